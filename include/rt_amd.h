@@ -1,0 +1,271 @@
+/*
+ * rt_amd.h — C ABI of the MI355X path-tracing library (librt_amd.so).
+ *
+ * The reference (YanjieShiFennec/RayTracing) has no FFI layer: its hot path is
+ * entered through the C++ call camera::render(world, file) (camera.h:31).  This
+ * ABI is the boundary that call is replaced by.  A host program (the drop-in
+ * C++ scene API under raytracing_amd/dropin, or any FFI) flattens its scene
+ * graph into an rt_scene_desc, uploads it once with rt_scene_create, and asks
+ * for samples with rt_render*.  Plain pointers and sizes only.
+ *
+ * Every function returns 0 on success and a negative RT_ERR_* code on failure;
+ * rt_last_error() returns a thread-local description of the last failure.
+ */
+#ifndef RT_AMD_H
+#define RT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_AMD_ABI_VERSION 1
+
+/* ---- error codes ------------------------------------------------------- */
+enum {
+    RT_OK = 0,
+    RT_ERR_ARG = -1,         /* bad argument / malformed descriptor          */
+    RT_ERR_HIP = -2,         /* a HIP runtime call failed (no GPU, OOM, ...) */
+    RT_ERR_UNSUPPORTED = -3, /* scene uses a feature outside the hot path    */
+    RT_ERR_IO = -4           /* scene file could not be read / written       */
+};
+
+/* ---- scene vocabulary (mirrors the reference's classes) ---------------- */
+enum { RT_PRIM_SPHERE = 0, RT_PRIM_QUAD = 1 };                       /* sphere.h:8, quad.h:9 */
+enum { RT_MAT_LAMBERTIAN = 0, RT_MAT_METAL = 1, RT_MAT_DIELECTRIC = 2,
+       RT_MAT_DIFFUSE_LIGHT = 3 };                                   /* material.h:24,49,68,107 */
+enum { RT_TEX_SOLID = 0, RT_TEX_CHECKER = 1, RT_TEX_IMAGE = 2,
+       RT_TEX_NOISE = 3 };                                           /* texture.h:16,31,56,81 */
+enum { RT_XF_TRANSLATE = 0, RT_XF_ROTATE_Y = 1, RT_XF_ROTATE_XYZ = 2,
+       RT_XF_SCALE = 3 };                                            /* hittable.h:51,100,212,313 */
+enum { RT_GROUP_LIST = 0, RT_GROUP_BVH = 1 };                        /* hittable_list.h:14, bvh.h:39 */
+
+/*
+ * One leaf primitive, in the order the reference would test it ("test order":
+ * insertion order inside a hittable_list, left-to-right leaf order inside a
+ * bvh_node).  The position of a primitive in rt_scene_desc::prims is its id;
+ * closest-hit ties are resolved as the reference's sequential scan would
+ * (sphere.h:58 open interval, quad.h:46 closed interval).
+ *
+ *   sphere: a = center1, b = center_vec (center2 - center1), c[0] = radius,
+ *           d = center2 as given to the moving-sphere constructor (only its
+ *           bounding box is built from it), flags bit0 = is_moving (sphere.h:11-26)
+ *   quad  : a = Q, b = u, c = v (object space, as passed to the constructor;
+ *           normal, D and w are derived by the library as quad.h:15-20 does)
+ */
+typedef struct rt_prim {
+    int32_t type;
+    int32_t material; /* index into rt_scene_desc::materials */
+    int32_t xform;    /* index into rt_scene_desc::chains, or -1 */
+    int32_t flags;
+    float a[3];
+    float b[3];
+    float c[3];
+    float d[3];
+} rt_prim; /* 64 bytes */
+
+#define RT_PRIM_FLAG_MOVING 1
+
+/* lambertian(tex) | metal(albedo, fuzz) | dielectric(ior) | diffuse_light(tex) */
+typedef struct rt_material {
+    int32_t type;
+    int32_t texture; /* lambertian / diffuse_light: index into textures; else -1 */
+    float albedo[3]; /* metal */
+    float param;     /* metal: fuzz (already clamped to <= 1); dielectric: refraction index */
+} rt_material;
+
+/* solid(color) | checker(inv_scale, even, odd) | image(image) | noise(scale, perlin) */
+typedef struct rt_texture {
+    int32_t type;
+    int32_t even, odd; /* checker: child texture indices */
+    int32_t perlin;    /* noise: index into perlins */
+    int32_t image;     /* image: index into images, -1 = file missing (texture.h:62) */
+    float color[3];    /* solid */
+    float scale;       /* checker: inv_scale (texture.h:33); noise: scale (texture.h:83) */
+} rt_texture;
+
+/* perlin.h:55-56 — only randvec and perm_x are read by perlin::noise (perlin.h:33). */
+typedef struct rt_perlin {
+    float randvec[256][3];
+    int32_t perm_x[256];
+} rt_perlin;
+
+/* rtw_stb_image.h:69-79 — 3 bytes per texel, row-major, already in the
+ * reference's "linear byte" form (gamma-2.2 decoded then 256*v quantised). */
+typedef struct rt_image {
+    int32_t width, height;
+    uint64_t offset; /* byte offset of texel (0,0) in rt_scene_desc::texels */
+} rt_image;
+
+typedef struct rt_xform_op {
+    int32_t type;
+    float p[3]; /* translate: offset; rotate_y: (deg,0,0); rotate_xyz: (a,b,g) deg; scale: factors */
+} rt_xform_op;
+
+/* A chain lists the wrappers around a primitive, innermost first:
+ * scaling(translate(rotate_xyz(box))) -> {rotate_xyz, translate, scale}. */
+typedef struct rt_xform_chain {
+    int32_t first_op, n_ops;
+} rt_xform_chain;
+
+/* Consecutive runs of prims: a plain list run, or the leaves of one bvh_node
+ * (bvh.h:48-75: the tree is the recursive median split of that run). */
+typedef struct rt_group {
+    int32_t kind;
+    int32_t first_prim, n_prims;
+    int32_t reserved;
+} rt_group;
+
+typedef struct rt_scene_desc {
+    uint32_t abi_version; /* RT_AMD_ABI_VERSION */
+    int32_t n_prims;
+    const rt_prim *prims;
+    int32_t n_groups;
+    const rt_group *groups;
+    int32_t n_materials;
+    const rt_material *materials;
+    int32_t n_textures;
+    const rt_texture *textures;
+    int32_t n_perlins;
+    const rt_perlin *perlins;
+    int32_t n_images;
+    const rt_image *images;
+    uint64_t n_texel_bytes;
+    const uint8_t *texels;
+    int32_t n_xform_ops;
+    const rt_xform_op *xform_ops;
+    int32_t n_chains;
+    const rt_xform_chain *chains;
+} rt_scene_desc;
+
+/* ---- camera (camera.h:15-29 public fields, same defaults expected) ------ */
+typedef struct rt_camera_desc {
+    float aspect_ratio;
+    int32_t image_width;
+    int32_t samples_per_pixel;
+    int32_t max_depth;
+    float background[3];
+    float vfov;
+    float lookfrom[3], lookat[3], vup[3];
+    float defocus_angle, focus_dist;
+} rt_camera_desc;
+
+/* Result of camera::initialize (camera.h:76-111). */
+typedef struct rt_camera_frame {
+    int32_t image_width, image_height;
+    float pixel_samples_scale;
+    float center[3], pixel00_loc[3], pixel_delta_u[3], pixel_delta_v[3];
+    float u[3], v[3], w[3];
+    float defocus_disk_u[3], defocus_disk_v[3];
+} rt_camera_frame;
+
+/* ---- rays / hits for the parity entry point ----------------------------- */
+typedef struct rt_ray {
+    float orig[3];
+    float dir[3];
+    float tm;
+} rt_ray;
+
+/* hit_record (hittable.h:10-26) plus the id of the closest primitive. */
+typedef struct rt_hit {
+    int32_t prim; /* index into rt_scene_desc::prims, -1 on miss */
+    int32_t front_face;
+    float t;
+    float p[3];
+    float normal[3];
+    float u, v;
+} rt_hit;
+
+/* ---- render options / statistics --------------------------------------- */
+enum { RT_MODE_MEGAKERNEL = 0, RT_MODE_WAVEFRONT = 1 };
+
+#define RT_RENDER_COUNTERS 1u      /* fill the per-test counters of rt_render_stats */
+#define RT_SCENE_FORCE_BVH 1u      /* rt_scene_create: build a BVH even for tiny scenes */
+#define RT_SCENE_FORCE_LINEAR 2u   /* never build a BVH (linear scan in test order)   */
+#define RT_SCENE_FORCE_GLOBAL 4u   /* keep scene arrays in HBM even if they fit LDS   */
+
+typedef struct rt_render_opts {
+    int32_t sample_begin; /* first global sample index rendered by this call */
+    int32_t sample_count; /* samples per pixel rendered by this call         */
+    uint32_t seed;        /* stream seed of the counter-based sampler        */
+    int32_t mode;         /* RT_MODE_*                                        */
+    uint32_t flags;       /* RT_RENDER_*                                      */
+    int32_t reserved[3];
+} rt_render_opts;
+
+typedef struct rt_render_stats {
+    uint64_t paths;        /* camera samples traced                          */
+    uint64_t rays;         /* closest-hit queries (camera + bounce segments) */
+    uint64_t box_tests;    /* the rest only with RT_RENDER_COUNTERS          */
+    uint64_t sphere_tests;
+    uint64_t sphere_hits;
+    uint64_t quad_tests;
+    uint64_t shades[4];    /* per RT_MAT_*                                   */
+    uint64_t noise_evals, image_evals, checker_evals;
+    double kernel_ms;      /* HIP-event time of the render kernels of this call */
+} rt_render_stats;
+
+typedef struct rt_scene_info {
+    int32_t n_prims, n_spheres, n_quads;
+    int32_t n_nodes;      /* 0 = linear scan */
+    int32_t bvh_depth;
+    int32_t lds_resident; /* 1 if geometry is staged into LDS by the kernels */
+    uint64_t device_bytes;
+} rt_scene_info;
+
+typedef struct rt_scene rt_scene; /* opaque: owns the device copy of one scene */
+
+/* ---- entry points -------------------------------------------------------- */
+
+const char *rt_last_error(void);
+int rt_abi_version(void);
+
+/* Number of visible HIP devices (0 if none / no driver). */
+int rt_device_count(void);
+
+/* camera::initialize (camera.h:76-111), same fp32 arithmetic. Host only. */
+int rt_camera_initialize(const rt_camera_desc *cam, rt_camera_frame *out);
+
+/* Replaces the scene half of camera::render's prologue: bakes instance
+ * wrappers (hittable.h:51-344) into world-space quads, derives the quad
+ * constants (quad.h:15-20), builds the traversal structure that stands in for
+ * bvh_node (bvh.h:48-75) / hittable_list (hittable_list.h:29-43) and copies
+ * everything to `device`.  The descriptor may be freed afterwards. */
+int rt_scene_create(const rt_scene_desc *desc, int device, uint32_t flags, rt_scene **out);
+int rt_scene_destroy(rt_scene *scene);
+int rt_scene_get_info(const rt_scene *scene, rt_scene_info *out);
+
+/* Replaces world.hit(r, interval(tmin, tmax), rec) (camera.h:148) for a batch
+ * of rays: closest hit per ray.  Host buffers; the library stages them. */
+int rt_trace_batch(rt_scene *scene, const rt_ray *rays, int64_t n_rays, float tmin, float tmax,
+                   rt_hit *hits);
+/* Same with device-resident buffers, enqueued on `stream` (a hipStream_t). */
+int rt_trace_batch_device(rt_scene *scene, const rt_ray *d_rays, int64_t n_rays, float tmin,
+                          float tmax, rt_hit *d_hits, void *stream);
+
+/* Replaces the sample loop of camera::render (camera.h:40-47) for samples
+ * [sample_begin, sample_begin+sample_count) of every pixel: ADDS the radiance
+ * sum of those samples to accum (image_height*image_width*3 floats, row-major
+ * RGB).  The caller applies 1/spp and write_color (rt_tonemap_u8). */
+int rt_render(rt_scene *scene, const rt_camera_desc *cam, const rt_render_opts *opts,
+              float *accum_host, rt_render_stats *stats);
+/* accum lives in device memory; kernels are enqueued on `stream`.  With
+ * stats == NULL the call does not synchronise. */
+int rt_render_device(rt_scene *scene, const rt_camera_desc *cam, const rt_render_opts *opts,
+                     float *d_accum, void *stream, rt_render_stats *stats);
+
+/* write_color / linear_to_gamma (color.h:11-32): rgb8 = int(256*clamp(sqrt(scale*c),0,0.999)). */
+int rt_tonemap_u8(const float *accum, int64_t n_pixels, float scale, uint8_t *rgb8);
+
+/* Scene files (.rtscene): a flat dump of rt_scene_desc used for fixtures. */
+int rt_scene_file_save(const rt_scene_desc *desc, const char *path);
+/* Loads into one malloc'd block; *out points into it; free with rt_scene_file_free. */
+int rt_scene_file_load(const char *path, rt_scene_desc **out);
+void rt_scene_file_free(rt_scene_desc *desc);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_AMD_H */

@@ -1,0 +1,118 @@
+/*
+ * rt_scene_io.h — header-only reader/writer of the .rtscene fixture format.
+ *
+ * A .rtscene file is a flat dump of an rt_scene_desc (rt_amd.h):
+ *   char     magic[8] = "RTSCENE1"
+ *   uint64_t counts[10] = { n_prims, n_groups, n_materials, n_textures, n_perlins,
+ *                           n_images, n_texel_bytes, n_xform_ops, n_chains, 0 }
+ *   then the arrays in that order, each padded to a multiple of 8 bytes.
+ * Shared by the library, the CPU oracle and the reference harness so that all
+ * three exchange scenes through one format.
+ */
+#ifndef RT_SCENE_IO_H
+#define RT_SCENE_IO_H
+
+#include "rt_amd.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace rtio {
+
+static const char kMagic[8] = {'R', 'T', 'S', 'C', 'E', 'N', 'E', '1'};
+
+inline size_t pad8(size_t n) { return (n + 7u) & ~size_t(7); }
+
+inline bool write_block(FILE *f, const void *p, size_t bytes) {
+    static const char zeros[8] = {0};
+    if (bytes && fwrite(p, 1, bytes, f) != bytes) return false;
+    size_t pad = pad8(bytes) - bytes;
+    return pad == 0 || fwrite(zeros, 1, pad, f) == pad;
+}
+
+inline int save(const rt_scene_desc *d, const char *path) {
+    FILE *f = fopen(path, "wb");
+    if (!f) return RT_ERR_IO;
+    uint64_t counts[10] = {(uint64_t)d->n_prims,     (uint64_t)d->n_groups,
+                           (uint64_t)d->n_materials, (uint64_t)d->n_textures,
+                           (uint64_t)d->n_perlins,   (uint64_t)d->n_images,
+                           d->n_texel_bytes,         (uint64_t)d->n_xform_ops,
+                           (uint64_t)d->n_chains,    0};
+    bool ok = fwrite(kMagic, 1, 8, f) == 8 && fwrite(counts, sizeof(uint64_t), 10, f) == 10;
+    ok = ok && write_block(f, d->prims, sizeof(rt_prim) * d->n_prims);
+    ok = ok && write_block(f, d->groups, sizeof(rt_group) * d->n_groups);
+    ok = ok && write_block(f, d->materials, sizeof(rt_material) * d->n_materials);
+    ok = ok && write_block(f, d->textures, sizeof(rt_texture) * d->n_textures);
+    ok = ok && write_block(f, d->perlins, sizeof(rt_perlin) * d->n_perlins);
+    ok = ok && write_block(f, d->images, sizeof(rt_image) * d->n_images);
+    ok = ok && write_block(f, d->texels, d->n_texel_bytes);
+    ok = ok && write_block(f, d->xform_ops, sizeof(rt_xform_op) * d->n_xform_ops);
+    ok = ok && write_block(f, d->chains, sizeof(rt_xform_chain) * d->n_chains);
+    ok = (fclose(f) == 0) && ok;
+    return ok ? RT_OK : RT_ERR_IO;
+}
+
+/* Loads the file into ONE malloc'd block that starts with the rt_scene_desc
+ * itself; free() of the returned pointer releases everything. */
+inline rt_scene_desc *load(const char *path) {
+    FILE *f = fopen(path, "rb");
+    if (!f) return nullptr;
+    char magic[8];
+    uint64_t c[10];
+    if (fread(magic, 1, 8, f) != 8 || memcmp(magic, kMagic, 8) != 0 ||
+        fread(c, sizeof(uint64_t), 10, f) != 10) {
+        fclose(f);
+        return nullptr;
+    }
+    const size_t sz[9] = {sizeof(rt_prim) * c[0],     sizeof(rt_group) * c[1],
+                          sizeof(rt_material) * c[2], sizeof(rt_texture) * c[3],
+                          sizeof(rt_perlin) * c[4],   sizeof(rt_image) * c[5],
+                          (size_t)c[6],               sizeof(rt_xform_op) * c[7],
+                          sizeof(rt_xform_chain) * c[8]};
+    size_t total = pad8(sizeof(rt_scene_desc));
+    for (int i = 0; i < 9; i++) total += pad8(sz[i]);
+    char *blk = (char *)malloc(total);
+    if (!blk) {
+        fclose(f);
+        return nullptr;
+    }
+    size_t payload = total - pad8(sizeof(rt_scene_desc));
+    if (fread(blk + pad8(sizeof(rt_scene_desc)), 1, payload, f) != payload) {
+        free(blk);
+        fclose(f);
+        return nullptr;
+    }
+    fclose(f);
+    rt_scene_desc *d = (rt_scene_desc *)blk;
+    memset(d, 0, sizeof(*d));
+    char *p = blk + pad8(sizeof(rt_scene_desc));
+    const void *ptr[9];
+    for (int i = 0; i < 9; i++) {
+        ptr[i] = sz[i] ? p : nullptr;
+        p += pad8(sz[i]);
+    }
+    d->abi_version = RT_AMD_ABI_VERSION;
+    d->n_prims = (int32_t)c[0];
+    d->prims = (const rt_prim *)ptr[0];
+    d->n_groups = (int32_t)c[1];
+    d->groups = (const rt_group *)ptr[1];
+    d->n_materials = (int32_t)c[2];
+    d->materials = (const rt_material *)ptr[2];
+    d->n_textures = (int32_t)c[3];
+    d->textures = (const rt_texture *)ptr[3];
+    d->n_perlins = (int32_t)c[4];
+    d->perlins = (const rt_perlin *)ptr[4];
+    d->n_images = (int32_t)c[5];
+    d->images = (const rt_image *)ptr[5];
+    d->n_texel_bytes = c[6];
+    d->texels = (const uint8_t *)ptr[6];
+    d->n_xform_ops = (int32_t)c[7];
+    d->xform_ops = (const rt_xform_op *)ptr[7];
+    d->n_chains = (int32_t)c[8];
+    d->chains = (const rt_xform_chain *)ptr[8];
+    return d;
+}
+
+} // namespace rtio
+#endif /* RT_SCENE_IO_H */
