@@ -259,6 +259,13 @@ int rt_render_device(rt_scene *scene, const rt_camera_desc *cam, const rt_render
 /* write_color / linear_to_gamma (color.h:11-32): rgb8 = int(256*clamp(sqrt(scale*c),0,0.999)). */
 int rt_tonemap_u8(const float *accum, int64_t n_pixels, float scale, uint8_t *rgb8);
 
+/* Per-launch timing of the render kernel: between begin and end the library
+ * brackets every render-kernel launch of this scene with HIP events on the
+ * stream it is launched on; end waits for them and returns the summed
+ * duration and the number of launches. */
+int rt_profile_begin(rt_scene *scene);
+int rt_profile_end(rt_scene *scene, double *total_ms, int *n_launches);
+
 /* Scene files (.rtscene): a flat dump of rt_scene_desc used for fixtures. */
 int rt_scene_file_save(const rt_scene_desc *desc, const char *path);
 /* Loads into one malloc'd block; *out points into it; free with rt_scene_file_free. */

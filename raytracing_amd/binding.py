@@ -1,0 +1,143 @@
+"""ctypes binding of raytracing_amd/lib/librt_amd.so (C ABI: include/rt_amd.h).
+
+This is the only way Python reaches the renderer; there is no Python or CPU
+implementation behind it.  A missing library or a missing GPU raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "librt_amd.so")
+
+# every symbol include/rt_amd.h declares
+EXPORTS = ["rt_last_error", "rt_abi_version", "rt_device_count", "rt_camera_initialize",
+           "rt_scene_create", "rt_scene_destroy", "rt_scene_get_info", "rt_trace_batch",
+           "rt_trace_batch_device", "rt_render", "rt_render_device", "rt_tonemap_u8",
+           "rt_profile_begin", "rt_profile_end", "rt_scene_file_save", "rt_scene_file_load",
+           "rt_scene_file_free"]
+
+
+class RtError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"librt_amd: error {code}: {message}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RtError(abi.RT_ERR_IO, f"{LIB_PATH} is missing: build it with "
+                          "`make -C raytracing_amd/csrc` (or __graft_entry__.build())")
+        L = C.CDLL(LIB_PATH)
+        L.rt_last_error.restype = C.c_char_p
+        L.rt_camera_initialize.argtypes = [C.POINTER(abi.CameraDesc), C.POINTER(abi.CameraFrame)]
+        L.rt_scene_create.argtypes = [C.POINTER(abi.SceneDesc), C.c_int, C.c_uint32,
+                                      C.POINTER(C.c_void_p)]
+        L.rt_scene_destroy.argtypes = [C.c_void_p]
+        L.rt_scene_get_info.argtypes = [C.c_void_p, C.POINTER(abi.SceneInfo)]
+        L.rt_trace_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
+                                     C.c_void_p]
+        L.rt_trace_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
+                                            C.c_void_p, C.c_void_p]
+        L.rt_render.argtypes = [C.c_void_p, C.POINTER(abi.CameraDesc), C.POINTER(abi.RenderOpts),
+                                C.c_void_p, C.POINTER(abi.RenderStats)]
+        L.rt_render_device.argtypes = [C.c_void_p, C.POINTER(abi.CameraDesc),
+                                       C.POINTER(abi.RenderOpts), C.c_void_p, C.c_void_p,
+                                       C.POINTER(abi.RenderStats)]
+        L.rt_tonemap_u8.argtypes = [C.c_void_p, C.c_int64, C.c_float, C.c_void_p]
+        L.rt_profile_begin.argtypes = [C.c_void_p]
+        L.rt_profile_end.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        L.rt_scene_file_save.argtypes = [C.POINTER(abi.SceneDesc), C.c_char_p]
+        L.rt_scene_file_load.argtypes = [C.c_char_p, C.POINTER(C.POINTER(abi.SceneDesc))]
+        L.rt_scene_file_free.argtypes = [C.POINTER(abi.SceneDesc)]
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != abi.RT_OK:
+        raise RtError(rc, lib().rt_last_error().decode())
+
+
+def device_count():
+    return lib().rt_device_count()
+
+
+def camera_initialize(cam):
+    f = abi.CameraFrame()
+    check(lib().rt_camera_initialize(C.byref(cam), C.byref(f)))
+    return f
+
+
+def tonemap_u8(accum, scale):
+    accum = np.ascontiguousarray(accum, np.float32)
+    out = np.zeros(accum.shape, np.uint8)
+    check(lib().rt_tonemap_u8(accum.ctypes.data, accum.size // 3, scale, out.ctypes.data))
+    return out
+
+
+class Scene:
+    """Device-resident scene (rt_scene_create .. rt_scene_destroy)."""
+
+    def __init__(self, arrays: abi.SceneArrays, device=0, flags=0):
+        self.arrays = arrays
+        d = arrays.desc()
+        h = C.c_void_p()
+        check(lib().rt_scene_create(C.byref(d), device, flags, C.byref(h)))
+        self.handle = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib().rt_scene_destroy(self.handle)
+            self.handle = None
+
+    __del__ = close
+
+    def info(self):
+        i = abi.SceneInfo()
+        check(lib().rt_scene_get_info(self.handle, C.byref(i)))
+        return i
+
+    def trace(self, rays, tmin=0.001, tmax=np.inf):
+        rays = np.ascontiguousarray(rays, abi.RAY_DT)
+        hits = np.zeros(len(rays), abi.HIT_DT)
+        check(lib().rt_trace_batch(self.handle, rays.ctypes.data, len(rays), tmin, tmax,
+                                   hits.ctypes.data))
+        return hits
+
+    def render(self, cam, sample_count, sample_begin=0, seed=0, counters=False, accum=None):
+        """Host-buffer render: returns (accum[H,W,3] fp32 sums, RenderStats)."""
+        H, W = cam.image_height(), cam.image_width
+        if accum is None:
+            accum = np.zeros((H, W, 3), np.float32)
+        o = abi.RenderOpts(sample_begin, sample_count, seed, abi.RT_MODE_MEGAKERNEL,
+                           abi.RT_RENDER_COUNTERS if counters else 0)
+        st = abi.RenderStats()
+        check(lib().rt_render(self.handle, C.byref(cam), C.byref(o), accum.ctypes.data, C.byref(st)))
+        return accum, st
+
+    def render_device(self, cam, sample_count, d_accum_ptr, stream=0, sample_begin=0, seed=0,
+                      counters=False, want_stats=False):
+        """Device-buffer render: d_accum_ptr is a device address (e.g. tensor.data_ptr())."""
+        o = abi.RenderOpts(sample_begin, sample_count, seed, abi.RT_MODE_MEGAKERNEL,
+                           abi.RT_RENDER_COUNTERS if counters else 0)
+        st = abi.RenderStats() if (want_stats or counters) else None
+        check(lib().rt_render_device(self.handle, C.byref(cam), C.byref(o), C.c_void_p(d_accum_ptr),
+                                     C.c_void_p(stream), C.byref(st) if st is not None else None))
+        return st
+
+    def profile_begin(self):
+        check(lib().rt_profile_begin(self.handle))
+
+    def profile_end(self):
+        ms, n = C.c_double(), C.c_int()
+        check(lib().rt_profile_end(self.handle, C.byref(ms), C.byref(n)))
+        return ms.value, n.value

@@ -1,0 +1,722 @@
+// rt_core.h — device-side core of the path tracer: math, sampler, intersection,
+// traversal, surface reconstruction, shading and the per-ray path step.
+//
+// Everything here is a plain inlined function over POD types so that the HIP
+// kernels (rt_kernels.hip) instantiate it for gfx950.  The arithmetic that
+// decides hit / miss / closest primitive is written operation for operation
+// like the reference (compile with -ffp-contract=off: a contracted h*h - a*c
+// changes t far beyond 1e-5 on the r = 1000 ground sphere); FMAs appear only
+// where they are written explicitly (bounding-box culling, which is
+// conservative by construction).
+#pragma once
+
+#include "rt_amd.h"
+
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define RT_HD __host__ __device__ __forceinline__
+#else
+#define RT_HD inline
+#endif
+
+namespace rtc {
+
+// ------------------------------------------------------------------------------------------
+// POD vector types (own types: identical layout on host and device)
+struct alignas(16) f4 {
+    float x, y, z, w;
+};
+struct alignas(16) i4 {
+    int x, y, z, w;
+};
+struct f3 {
+    float x, y, z;
+};
+
+RT_HD f3 mk(float x, float y, float z) {
+    f3 r;
+    r.x = x;
+    r.y = y;
+    r.z = z;
+    return r;
+}
+RT_HD f3 operator-(f3 a) { return mk(-a.x, -a.y, -a.z); }
+RT_HD f3 operator+(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+RT_HD f3 operator-(f3 a, f3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+RT_HD f3 operator*(f3 a, f3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+RT_HD f3 operator/(f3 a, f3 b) { return mk(a.x / b.x, a.y / b.y, a.z / b.z); }
+RT_HD f3 operator*(float t, f3 v) { return mk(t * v.x, t * v.y, t * v.z); }
+RT_HD f3 operator*(f3 v, float t) { return t * v; }
+RT_HD f3 operator/(f3 v, float t) { return (1.0f / t) * v; } // vec3.h:107: multiply by the reciprocal
+RT_HD float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RT_HD float len2(f3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+RT_HD float len(f3 a) { return sqrtf(len2(a)); }
+RT_HD f3 cross(f3 a, f3 b) {
+    return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+RT_HD f3 unit(f3 v) { return v / len(v); }
+RT_HD f3 xyz(f4 v) { return mk(v.x, v.y, v.z); }
+
+#define RT_PI 3.1415926535897932385f
+#define RT_INF __builtin_huge_valf()
+
+struct Ray {
+    f3 o, d;
+    float tm;
+};
+
+// ------------------------------------------------------------------------------------------
+// Scene as the kernels see it.  All pointers are device pointers.
+//
+// slots: one per primitive, slot_f4 x 16 bytes each.
+//   sphere: {c1.x c1.y c1.z radius} {cv.x cv.y cv.z 0}
+//   quad  : {n.x n.y n.z D} {Q.x Q.y Q.z w.x} {w.y w.z u.x u.y} {u.z v.x v.y v.z}
+// meta : per slot {type, material, chain (-1 none), prim id}
+// nodes: BVH2 with the two child boxes stored in the parent, 64 bytes:
+//   {lo0.x lo0.y lo0.z hi0.x} {hi0.y hi0.z lo1.x lo1.y} {lo1.z hi1.x hi1.y hi1.z} {ref0 ref1 - -}
+//   ref >= 0: inner node index; ref < 0: leaf, ~ref = slot*2 + type
+// xf   : 3 x 16 bytes per wrapper op {type p0 p1 p2} {sa ca sb cb} {sg cg - -}
+enum { TRAV_LINEAR = 0, TRAV_BVH = 1 };
+
+struct DevScene {
+    const f4 *slots;
+    const i4 *meta;
+    const f4 *nodes;
+    const f4 *xf;
+    const int *chain_first; // chain c covers ops [chain_first[c], chain_first[c+1])
+    const rt_material *materials;
+    const rt_texture *textures;
+    const rt_perlin *perlins;
+    const rt_image *images;
+    const uint8_t *texels;
+    int n_slots;
+    int n_nodes;
+    int slot_f4;   // 2 (spheres only) or 4
+    int traversal; // TRAV_*
+    int n_chains;
+    int n_xf_ops;
+};
+
+struct DevCamera {
+    rt_camera_frame f;
+    float background[3];
+    float defocus_angle;
+    int max_depth;
+};
+
+struct Counters {
+    unsigned long long box_tests, sphere_tests, sphere_hits, quad_tests;
+    unsigned long long shades[4];
+    unsigned long long noise_evals, image_evals, checker_evals;
+};
+
+template <bool COUNT> struct Cnt {
+    unsigned box = 0, sph = 0, sphh = 0, quad = 0, sh0 = 0, sh1 = 0, sh2 = 0, sh3 = 0, noise = 0, img = 0,
+             chk = 0;
+};
+template <> struct Cnt<false> {};
+
+#define RT_COUNT(field)                                                                            \
+    if constexpr (COUNT) cn.field++
+
+// ------------------------------------------------------------------------------------------
+// Counter-based sampler.  Key = (seed, pixel, global sample index); numbers within
+// a path come from a 32-bit LCG with a PCG (RXS-M-XS) output permutation.  The
+// image therefore does not depend on how paths are scheduled or on the GPU count.
+RT_HD uint32_t mix32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7feb352du;
+    x ^= x >> 15;
+    x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+struct Rng {
+    uint32_t s;
+};
+RT_HD Rng rng_seed(uint32_t seed, uint32_t pixel, uint32_t sample) {
+    Rng r;
+    r.s = mix32(pixel * 0x9E3779B9u + mix32(sample * 0x85EBCA6Bu + mix32(seed + 0x68E31DA4u)));
+    return r;
+}
+RT_HD float rng_next(Rng &r) { // uniform in [0,1), 24 bits (rt_constants.h:28-33 draws 32 and rounds)
+    r.s = r.s * 747796405u + 2891336453u;
+    uint32_t w = ((r.s >> ((r.s >> 28u) + 4u)) ^ r.s) * 277803737u;
+    w = (w >> 22u) ^ w;
+    return float(w >> 8) * (1.0f / 16777216.0f);
+}
+
+RT_HD void sincos_2pi(float u, float &s, float &c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    sincospif(2.0f * u, &s, &c);
+#else
+    s = sinf(2.0f * RT_PI * u);
+    c = cosf(2.0f * RT_PI * u);
+#endif
+}
+
+// Uniform direction on the unit sphere.  The reference normalises a point drawn
+// by rejection from the unit ball (vec3.h:138-149); the distribution is the same.
+RT_HD f3 sample_unit_vector(Rng &rng) {
+    float z = 1.0f - 2.0f * rng_next(rng);
+    float s, c;
+    sincos_2pi(rng_next(rng), s, c);
+    float rr = sqrtf(fmaxf(0.0f, 1.0f - z * z));
+    return mk(rr * c, rr * s, z);
+}
+// Uniform point in the unit disk (vec3.h:130-136 uses rejection).
+RT_HD void sample_unit_disk(Rng &rng, float &px, float &py) {
+    float r = sqrtf(rng_next(rng));
+    float s, c;
+    sincos_2pi(rng_next(rng), s, c);
+    px = r * c;
+    py = r * s;
+}
+
+// ------------------------------------------------------------------------------------------
+// Primitive tests.  Return the candidate parameter only; the surface is rebuilt
+// once, for the winner (surface_at).
+
+// sphere::hit up to the accepted root (sphere.h:40-63).  The interval is open.
+RT_HD bool sphere_test(f4 g0, f4 g1, f3 o, f3 d, float tm, float tmin, float tmax, float &t_out) {
+    f3 center = xyz(g0) + tm * xyz(g1); // sphere.h:93 (static spheres carry a zero center_vec)
+    f3 oc = center - o;
+    float a = len2(d);
+    float h = dot(d, oc);
+    float c = len2(oc) - g0.w * g0.w;
+    float discriminant = h * h - a * c;
+    if (discriminant < 0.0f) return false;
+    float sqrtd = sqrtf(discriminant);
+    float root = (h - sqrtd) / a;
+    if (!(tmin < root && root < tmax)) {
+        root = (h + sqrtd) / a;
+        if (!(tmin < root && root < tmax)) return false;
+    }
+    t_out = root;
+    return true;
+}
+
+// quad::hit + is_interior (quad.h:38-69, 80-91).  The interval is closed.
+RT_HD bool quad_test(f4 g0, f4 g1, f4 g2, f4 g3, f3 o, f3 d, float tmin, float tmax, float &t_out,
+                     float &alpha_out, float &beta_out) {
+    f3 n = xyz(g0);
+    float denominator = dot(n, d);
+    if (fabsf(denominator) < 1e-8f) return false;
+    float t = (g0.w - dot(n, o)) / denominator;
+    if (!(tmin <= t && t <= tmax)) return false;
+    f3 Q = xyz(g1);
+    f3 w = mk(g1.w, g2.x, g2.y);
+    f3 u = mk(g2.z, g2.w, g3.x);
+    f3 v = mk(g3.y, g3.z, g3.w);
+    f3 planar = (o + t * d) - Q;
+    float alpha = dot(w, cross(planar, v));
+    float beta = dot(w, cross(u, planar));
+    if (!(0.0f <= alpha && alpha <= 1.0f) || !(0.0f <= beta && beta <= 1.0f)) return false;
+    t_out = t;
+    alpha_out = alpha;
+    beta_out = beta;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------
+// Instance wrappers (hittable.h:51-344), applied to the ray at run time exactly
+// as the reference does; used by the linear traversal, where it costs one ray
+// transform per wrapped object.
+RT_HD f3 rot_y_ccw(f4 a, f3 v) { // hittable.h:162-166   a = {sa ca sb cb}
+    float vx = a.w * v.x + a.z * v.z;
+    float vz = -a.z * v.x + a.w * v.z;
+    return mk(vx, v.y, vz);
+}
+RT_HD f3 rot_y_cw(f4 a, f3 v) { // hittable.h:169-173
+    float vx = a.w * v.x - a.z * v.z;
+    float vz = a.z * v.x + a.w * v.z;
+    return mk(vx, v.y, vz);
+}
+RT_HD f3 rot_xyz_ccw(f4 a, f4 b, f3 v) { // hittable.h:284-295   b = {sg cg - -}
+    float sa = a.x, ca = a.y, sb = a.z, cb = a.w, sg = b.x, cg = b.y;
+    float vx = cb * cg * v.x + (sa * sb * cg - sg * ca) * v.y + (sb * ca * cg + sa * sg) * v.z;
+    float vy = cb * sg * v.x + (ca * cg + sa * sb * sg) * v.y + (-sa * cg + sg * sb * ca) * v.z;
+    float vz = -sb * v.x + sa * cb * v.y + ca * cb * v.z;
+    return mk(vx, vy, vz);
+}
+RT_HD f3 rot_xyz_cw(f4 a, f4 b, f3 v) { // hittable.h:298-309
+    float sa = a.x, ca = a.y, sb = a.z, cb = a.w, sg = b.x, cg = b.y;
+    float vx = cb * cg * v.x + sg * cb * v.y - sb * v.z;
+    float vy = (sa * sb * cg - sg * ca) * v.x + (sa * sb * sg + ca * cg) * v.y + sa * cb * v.z;
+    float vz = (sb * ca * cg + sa * sg) * v.x + (sb * sg * ca - sa * cg) * v.y + ca * cb * v.z;
+    return mk(vx, vy, vz);
+}
+
+// world ray -> object ray: outermost wrapper first.
+RT_HD void chain_ray_to_object(const DevScene &sc, int chain, f3 &o, f3 &d) {
+    int first = sc.chain_first[chain], last = sc.chain_first[chain + 1];
+    for (int k = last - 1; k >= first; k--) {
+        f4 op = sc.xf[3 * k], a = sc.xf[3 * k + 1], b = sc.xf[3 * k + 2];
+        int type = __builtin_bit_cast(int, op.x);
+        f3 p = mk(op.y, op.z, op.w);
+        if (type == RT_XF_TRANSLATE) {
+            o = o - p;
+        } else if (type == RT_XF_ROTATE_Y) {
+            o = rot_y_cw(a, o);
+            d = rot_y_cw(a, d);
+        } else if (type == RT_XF_ROTATE_XYZ) {
+            o = rot_xyz_cw(a, b, o);
+            d = rot_xyz_cw(a, b, d);
+        } else {
+            o = o / p;
+            d = d / p;
+        }
+    }
+}
+// object-space hit point and normal -> world: innermost wrapper first.
+RT_HD void chain_hit_to_world(const DevScene &sc, int chain, f3 &p, f3 &n) {
+    int first = sc.chain_first[chain], last = sc.chain_first[chain + 1];
+    for (int k = first; k < last; k++) {
+        f4 op = sc.xf[3 * k], a = sc.xf[3 * k + 1], b = sc.xf[3 * k + 2];
+        int type = __builtin_bit_cast(int, op.x);
+        f3 s = mk(op.y, op.z, op.w);
+        if (type == RT_XF_TRANSLATE) {
+            p = p + s;
+        } else if (type == RT_XF_ROTATE_Y) {
+            p = rot_y_ccw(a, p);
+            n = rot_y_ccw(a, n);
+        } else if (type == RT_XF_ROTATE_XYZ) {
+            p = rot_xyz_ccw(a, b, p);
+            n = rot_xyz_ccw(a, b, n);
+        } else {
+            p = p * s;
+            n = unit(n / s);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Traversal
+struct TraceHit {
+    float t;
+    int slot; // -1: miss
+};
+
+// hittable_list::hit (hittable_list.h:29-43): scan in test order with a shrinking
+// interval.  `slots` may point to LDS or HBM.
+template <bool COUNT>
+RT_HD TraceHit trace_linear(const DevScene &sc, const f4 *slots, const i4 *meta, const Ray &r, float tmin,
+                            float tmax, Cnt<COUNT> &cn) {
+    TraceHit best;
+    best.t = tmax;
+    best.slot = -1;
+    int cur_chain = -1;
+    f3 o = r.o, d = r.d;
+    const int stride = sc.slot_f4;
+    for (int s = 0; s < sc.n_slots; s++) {
+        i4 m = meta[s];
+        if (m.z != cur_chain) {
+            cur_chain = m.z;
+            o = r.o;
+            d = r.d;
+            if (cur_chain >= 0) chain_ray_to_object(sc, cur_chain, o, d);
+        }
+        const f4 *g = slots + (size_t)s * stride;
+        float t, al, be;
+        bool h;
+        if (m.x == RT_PRIM_SPHERE) {
+            RT_COUNT(sph);
+            h = sphere_test(g[0], g[1], o, d, r.tm, tmin, best.t, t);
+            if constexpr (COUNT) cn.sphh += h ? 1 : 0;
+        } else {
+            RT_COUNT(quad);
+            h = quad_test(g[0], g[1], g[2], g[3], o, d, tmin, best.t, t, al, be);
+        }
+        if (h) {
+            best.t = t;
+            best.slot = s;
+        }
+    }
+    return best;
+}
+
+// Decides between two candidates with the same t as the reference's sequential
+// scan would: a later quad replaces (closed interval, quad.h:46), a later
+// sphere does not (open interval, sphere.h:58).
+RT_HD bool tie_prefers_candidate(int cand_id, bool cand_is_quad, int best_id, bool best_is_quad) {
+    if (best_id < 0) return cand_is_quad; // t == tmax: only the closed interval admits it
+    bool cand_later = cand_id > best_id;
+    bool later_is_quad = cand_later ? cand_is_quad : best_is_quad;
+    return later_is_quad ? cand_later : !cand_later;
+}
+
+struct BoxRay { // per-ray constants of the slab test
+    f3 inv;     // 1/d (a zero component is replaced by a huge finite reciprocal)
+    f3 onear;   // -(o*inv) - E : added when computing entry parameters
+    f3 ofar;    // -(o*inv) + E : added when computing exit parameters
+};
+RT_HD float safe_rcp(float d) {
+    // |d| below 1e-30 would overflow; a slab that the ray runs (almost) parallel to
+    // then yields +-huge parameters of the right sign, which is what the test needs.
+    float ad = fabsf(d);
+    float m = ad < 1e-30f ? 1e-30f : ad;
+    return copysignf(1.0f / m, d);
+}
+RT_HD BoxRay make_box_ray(const Ray &r) {
+    BoxRay b;
+    b.inv = mk(safe_rcp(r.d.x), safe_rcp(r.d.y), safe_rcp(r.d.z));
+    f3 oi = r.o * b.inv;
+    // fma(plane, inv, -o*inv) carries an absolute error of about 2^-24 |o*inv| from
+    // the rounded product; E widens the interval by 2^-21 of that magnitude.
+    const float k = 4.76837158e-7f;
+    f3 e = mk(fabsf(oi.x) * k, fabsf(oi.y) * k, fabsf(oi.z) * k);
+    b.onear = mk(-oi.x - e.x, -oi.y - e.y, -oi.z - e.z);
+    b.ofar = mk(-oi.x + e.x, -oi.y + e.y, -oi.z + e.z);
+    return b;
+}
+// Conservative ray/box overlap on [tmin, tmax]: returns the (slightly early) entry
+// parameter, or +inf when the box is missed.  Boxes are padded at build time.
+RT_HD float box_entry(f3 lo, f3 hi, const BoxRay &b, float tmin, float tmax) {
+    float ax = __builtin_fmaf(lo.x, b.inv.x, b.onear.x), bx = __builtin_fmaf(hi.x, b.inv.x, b.onear.x);
+    float ay = __builtin_fmaf(lo.y, b.inv.y, b.onear.y), by = __builtin_fmaf(hi.y, b.inv.y, b.onear.y);
+    float az = __builtin_fmaf(lo.z, b.inv.z, b.onear.z), bz = __builtin_fmaf(hi.z, b.inv.z, b.onear.z);
+    float cx = __builtin_fmaf(lo.x, b.inv.x, b.ofar.x), dx = __builtin_fmaf(hi.x, b.inv.x, b.ofar.x);
+    float cy = __builtin_fmaf(lo.y, b.inv.y, b.ofar.y), dy = __builtin_fmaf(hi.y, b.inv.y, b.ofar.y);
+    float cz = __builtin_fmaf(lo.z, b.inv.z, b.ofar.z), dz = __builtin_fmaf(hi.z, b.inv.z, b.ofar.z);
+    float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
+    float tf = fminf(fminf(fmaxf(cx, dx), fmaxf(cy, dy)), fminf(fmaxf(cz, dz), tmax));
+    // relative slack for the rounding of the fma results themselves
+    float slack = 9.5367431640625e-7f * fmaxf(fabsf(tn), fabsf(tf));
+    return (tn <= tf + slack) ? tn : RT_INF;
+}
+
+#ifndef RT_STACK_DEPTH
+#define RT_STACK_DEPTH 32
+#endif
+
+// BVH traversal, near child first.  StackT is the element type of the per-lane
+// stack, STACK_STRIDE the distance (in elements) between two levels of one lane.
+template <bool COUNT, typename StackT>
+RT_HD TraceHit trace_bvh(const DevScene &sc, const f4 *slots, const f4 *nodes, const i4 *meta, const Ray &r,
+                         float tmin, float tmax, StackT *stack, int stack_stride, Cnt<COUNT> &cn) {
+    TraceHit best;
+    best.t = tmax;
+    best.slot = -1;
+    bool best_is_quad = false;
+    const BoxRay br = make_box_ray(r);
+    const int stride = sc.slot_f4;
+    int sp = 0;
+    int ref = 0; // root
+    for (;;) {
+        if (ref >= 0) {
+            const f4 *n = nodes + (size_t)ref * 4;
+            f4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+            if constexpr (COUNT) cn.box += 2;
+            float e0 = box_entry(mk(n0.x, n0.y, n0.z), mk(n0.w, n1.x, n1.y), br, tmin, best.t);
+            float e1 = box_entry(mk(n1.z, n1.w, n2.x), mk(n2.y, n2.z, n2.w), br, tmin, best.t);
+            int r0 = __builtin_bit_cast(int, n3.x), r1 = __builtin_bit_cast(int, n3.y);
+            bool h0 = e0 < RT_INF, h1 = e1 < RT_INF;
+            if (h0 && h1) {
+                bool swap = e1 < e0;
+                int nearr = swap ? r1 : r0, farr = swap ? r0 : r1;
+                stack[sp * stack_stride] = (StackT)farr;
+                sp++;
+                ref = nearr;
+                continue;
+            } else if (h0 || h1) {
+                ref = h0 ? r0 : r1;
+                continue;
+            }
+        } else {
+            int code = ~ref;
+            int s = code >> 1;
+            bool is_quad = (code & 1) != 0;
+            const f4 *g = slots + (size_t)s * stride;
+            float t, al, be;
+            bool h;
+            // test against the closed interval [tmin.., best.t] and sort out equality below
+            if (!is_quad) {
+                RT_COUNT(sph);
+                h = sphere_test(g[0], g[1], r.o, r.d, r.tm, tmin, RT_INF, t);
+                if constexpr (COUNT) cn.sphh += h ? 1 : 0;
+                h = h && t <= best.t;
+            } else {
+                RT_COUNT(quad);
+                h = quad_test(g[0], g[1], g[2], g[3], r.o, r.d, tmin, best.t, t, al, be);
+            }
+            if (h) {
+                bool take = t < best.t;
+                if (!take) { // t == best.t: rare
+                    int cid = meta[s].w;
+                    int bid = best.slot >= 0 ? meta[best.slot].w : -1;
+                    take = tie_prefers_candidate(cid, is_quad, bid, best_is_quad);
+                }
+                if (take) {
+                    best.t = t;
+                    best.slot = s;
+                    best_is_quad = is_quad;
+                }
+            }
+        }
+        if (sp == 0) break;
+        sp--;
+        ref = (int)stack[sp * stack_stride];
+    }
+    return best;
+}
+
+// ------------------------------------------------------------------------------------------
+// Surface reconstruction for the winning primitive (the tail of sphere::hit /
+// quad::hit, then the wrappers' way back: hittable.h:66,146-148,264-266,328-331).
+struct Surf {
+    f3 p, n;       // world-space hit point and shading normal (against the ray)
+    f3 outward;    // spheres: object-space outward unit normal (for get_sphere_uv)
+    float u, v;    // quads: alpha, beta
+    int material, prim, type;
+    bool front;
+};
+
+RT_HD void sphere_uv(f3 p, float &u, float &v) { // sphere.h:96-113
+    float theta = acosf(-p.y);
+    float phi = atan2f(-p.z, p.x) + RT_PI;
+    u = phi / (2.0f * RT_PI);
+    v = theta / RT_PI;
+}
+
+RT_HD Surf surface_at(const DevScene &sc, const f4 *slots, const i4 *meta, const Ray &r, TraceHit h) {
+    Surf s;
+    i4 m = meta[h.slot];
+    s.type = m.x;
+    s.material = m.y;
+    s.prim = m.w;
+    f3 o = r.o, d = r.d;
+    if (m.z >= 0) chain_ray_to_object(sc, m.z, o, d);
+    const f4 *g = slots + (size_t)h.slot * sc.slot_f4;
+    f3 p = o + h.t * d; // ray.h:20
+    f3 outward;
+    s.u = 0.0f;
+    s.v = 0.0f;
+    if (m.x == RT_PRIM_SPHERE) {
+        f4 g0 = g[0], g1 = g[1];
+        f3 center = xyz(g0) + r.tm * xyz(g1);
+        outward = (p - center) / g0.w; // sphere.h:68
+        s.outward = outward;
+    } else {
+        f4 g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
+        outward = xyz(g0);
+        s.outward = outward;
+        f3 planar = p - xyz(g1);
+        f3 w = mk(g1.w, g2.x, g2.y);
+        f3 u = mk(g2.z, g2.w, g3.x);
+        f3 v = mk(g3.y, g3.z, g3.w);
+        s.u = dot(w, cross(planar, v));
+        s.v = dot(w, cross(u, planar));
+    }
+    s.front = dot(d, outward) < 0; // hittable.h:20-25
+    f3 n = s.front ? outward : -outward;
+    if (m.z >= 0) chain_hit_to_world(sc, m.z, p, n);
+    s.p = p;
+    s.n = n;
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------
+// Textures (texture.h:16-95, perlin.h:17-95)
+RT_HD float perlin_noise(const rt_perlin &pn, f3 p) {
+    float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
+    float u = p.x - fx, v = p.y - fy, w = p.z - fz;
+    int i = int(fx), j = int(fy), k = int(fz);
+    float uu = u * u * (3 - 2 * u);
+    float vv = v * v * (3 - 2 * v);
+    float ww = w * w * (3 - 2 * w);
+    // the reference hashes all three axes through perm_x (perlin.h:33)
+    int pi0 = pn.perm_x[i & 255], pi1 = pn.perm_x[(i + 1) & 255];
+    int pj0 = pn.perm_x[j & 255], pj1 = pn.perm_x[(j + 1) & 255];
+    int pk0 = pn.perm_x[k & 255], pk1 = pn.perm_x[(k + 1) & 255];
+    float accum = 0.0f;
+#pragma unroll
+    for (int di = 0; di < 2; di++)
+#pragma unroll
+        for (int dj = 0; dj < 2; dj++)
+#pragma unroll
+            for (int dk = 0; dk < 2; dk++) {
+                int idx = (di ? pi1 : pi0) ^ (dj ? pj1 : pj0) ^ (dk ? pk1 : pk0);
+                f3 c = mk(pn.randvec[idx][0], pn.randvec[idx][1], pn.randvec[idx][2]);
+                f3 wv = mk(u - di, v - dj, w - dk);
+                accum += (di * uu + (1 - di) * (1 - uu)) * (dj * vv + (1 - dj) * (1 - vv)) *
+                         (dk * ww + (1 - dk) * (1 - ww)) * dot(c, wv);
+            }
+    return accum;
+}
+RT_HD float perlin_turb(const rt_perlin &pn, f3 p, int depth) {
+    float accum = 0.0f;
+    float weight = 1.0f;
+    for (int i = 0; i < depth; i++) {
+        accum += weight * perlin_noise(pn, p);
+        weight *= 0.5f;
+        p = mk(p.x * 2, p.y * 2, p.z * 2);
+    }
+    return fabsf(accum);
+}
+
+template <bool COUNT> RT_HD f3 texture_value(const DevScene &sc, int tex, const Surf &s, Cnt<COUNT> &cn) {
+    const rt_texture *t = &sc.textures[tex];
+    for (int guard = 0; guard < 16 && t->type == RT_TEX_CHECKER; guard++) { // texture.h:40-47
+        RT_COUNT(chk);
+        int xi = int(floorf(t->scale * s.p.x));
+        int yi = int(floorf(t->scale * s.p.y));
+        int zi = int(floorf(t->scale * s.p.z));
+        bool is_even = (xi + yi + zi) % 2 == 0;
+        t = &sc.textures[is_even ? t->even : t->odd];
+    }
+    if (t->type == RT_TEX_SOLID) return mk(t->color[0], t->color[1], t->color[2]);
+    if (t->type == RT_TEX_NOISE) { // texture.h:85-90
+        RT_COUNT(noise);
+        float ph = t->scale * s.p.z + 10.0f * perlin_turb(sc.perlins[t->perlin], s.p, 7);
+        return mk(0.5f, 0.5f, 0.5f) * (1.0f + sinf(ph));
+    }
+    if (t->type == RT_TEX_IMAGE) { // texture.h:60-74, rtw_stb_image.h:69-94
+        RT_COUNT(img);
+        if (t->image < 0) return mk(0.0f, 0.0f, 1.0f);
+        float u = s.u, v = s.v;
+        if (s.type == RT_PRIM_SPHERE) sphere_uv(s.outward, u, v);
+        rt_image im = sc.images[t->image];
+        u = u < 0.0f ? 0.0f : (u > 1.0f ? 1.0f : u);
+        float vc = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+        v = 1.0f - vc;
+        int i = int(u * im.width);
+        int j = int(v * im.height);
+        i = i < 0 ? 0 : (i < im.width ? i : im.width - 1);
+        j = j < 0 ? 0 : (j < im.height ? j : im.height - 1);
+        const uint8_t *px = sc.texels + im.offset + ((size_t)j * im.width + i) * 3;
+        float cs = 1.0f / 255.0f;
+        return mk(cs * px[0], cs * px[1], cs * px[2]);
+    }
+    return mk(0.0f, 0.0f, 0.0f);
+}
+
+// ------------------------------------------------------------------------------------------
+// Camera ray (camera.h:113-137)
+RT_HD Ray camera_ray(const DevCamera &cam, int i, int j, Rng &rng) {
+    const rt_camera_frame &f = cam.f;
+    float dx = rng_next(rng) - 0.5f;
+    float dy = rng_next(rng) - 0.5f;
+    f3 p00 = mk(f.pixel00_loc[0], f.pixel00_loc[1], f.pixel00_loc[2]);
+    f3 du = mk(f.pixel_delta_u[0], f.pixel_delta_u[1], f.pixel_delta_u[2]);
+    f3 dv = mk(f.pixel_delta_v[0], f.pixel_delta_v[1], f.pixel_delta_v[2]);
+    f3 pixel_sample = p00 + ((i + dx) * du) + ((j + dy) * dv);
+    f3 center = mk(f.center[0], f.center[1], f.center[2]);
+    f3 origin = center;
+    if (!(cam.defocus_angle <= 0)) {
+        float px, py;
+        sample_unit_disk(rng, px, py);
+        f3 ddu = mk(f.defocus_disk_u[0], f.defocus_disk_u[1], f.defocus_disk_u[2]);
+        f3 ddv = mk(f.defocus_disk_v[0], f.defocus_disk_v[1], f.defocus_disk_v[2]);
+        origin = center + (px * ddu) + (py * ddv);
+    }
+    Ray r;
+    r.o = origin;
+    r.d = pixel_sample - origin;
+    r.tm = rng_next(rng);
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------
+// One bounce of ray_color (camera.h:139-174) in iterative form: radiance
+// L += beta * emitted, beta *= attenuation.  The recursion's
+// e0 + a0*(e1 + a1*(...)) and this running product differ by rounding only.
+struct PathState {
+    Ray ray;
+    f3 beta, L;
+    Rng rng;
+    int depth; // bounces left
+};
+
+RT_HD f3 reflect(f3 v, f3 n) { return v - 2.0f * dot(v, n) * n; } // vec3.h:163
+RT_HD f3 refract(f3 uv, f3 n, float etai_over_etat) {             // vec3.h:169
+    float cos_theta = fminf(dot(-uv, n), 1.0f);
+    f3 r_out_perp = etai_over_etat * (uv + cos_theta * n);
+    f3 r_out_parallel = -sqrtf(fabsf(1.0f - len2(r_out_perp))) * n;
+    return r_out_perp + r_out_parallel;
+}
+RT_HD float schlick(float cosine, float ri) { // material.h:97-103
+    float r0 = (1.0f - ri) / (1.0f + ri);
+    r0 = r0 * r0;
+    float x = 1.0f - cosine;
+    float x2 = x * x;
+    return r0 + (1.0f - r0) * (x2 * x2 * x);
+}
+
+// Returns true while the path continues.
+template <bool COUNT>
+RT_HD bool shade_hit(const DevScene &sc, const DevCamera &cam, PathState &ps, const Surf &s, Cnt<COUNT> &cn) {
+    const rt_material m = sc.materials[s.material];
+    if (m.type == RT_MAT_DIFFUSE_LIGHT) { // material.h:113-115: emits on both faces, never scatters
+        RT_COUNT(sh3);
+        ps.L = ps.L + ps.beta * texture_value<COUNT>(sc, m.texture, s, cn);
+        return false;
+    }
+    f3 dir, att;
+    if (m.type == RT_MAT_LAMBERTIAN) { // material.h:30-42
+        RT_COUNT(sh0);
+        dir = s.n + sample_unit_vector(ps.rng);
+        if (fabsf(dir.x) < 1e-8f && fabsf(dir.y) < 1e-8f && fabsf(dir.z) < 1e-8f) dir = s.n;
+        att = texture_value<COUNT>(sc, m.texture, s, cn);
+    } else if (m.type == RT_MAT_METAL) { // material.h:53-60
+        RT_COUNT(sh1);
+        f3 reflected = reflect(ps.ray.d, s.n);
+        dir = unit(reflected) + (m.param * sample_unit_vector(ps.rng));
+        att = mk(m.albedo[0], m.albedo[1], m.albedo[2]);
+        if (!(dot(dir, s.n) > 0)) return false; // absorbed: contributes nothing
+    } else { // dielectric, material.h:72-90
+        RT_COUNT(sh2);
+        att = mk(1.0f, 1.0f, 1.0f);
+        float ri = s.front ? (1.0f / m.param) : m.param;
+        f3 unit_direction = unit(ps.ray.d);
+        float cos_theta = fminf(dot(-unit_direction, s.n), 1.0f);
+        float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+        bool cannot_refract = ri * sin_theta > 1.0f;
+        float xi = rng_next(ps.rng);
+        if (cannot_refract || schlick(cos_theta, ri) > xi)
+            dir = reflect(unit_direction, s.n);
+        else
+            dir = refract(unit_direction, s.n, ri);
+    }
+    ps.beta = ps.beta * att;
+    ps.ray.o = s.p;
+    ps.ray.d = dir;
+    return true;
+}
+
+// Starts the path of (pixel, global sample index): camera.h:44-46.
+RT_HD PathState path_start(const DevCamera &cam, uint32_t seed, unsigned pixel, unsigned sample) {
+    PathState ps;
+    int py = (int)(pixel / (unsigned)cam.f.image_width);
+    int px = (int)(pixel - (unsigned)py * (unsigned)cam.f.image_width);
+    ps.rng = rng_seed(seed, pixel, sample);
+    ps.ray = camera_ray(cam, px, py, ps.rng);
+    ps.beta = mk(1.0f, 1.0f, 1.0f);
+    ps.L = mk(0.0f, 0.0f, 0.0f);
+    ps.depth = cam.max_depth;
+    return ps;
+}
+
+// One segment of ray_color: trace, then miss / emit / scatter.  Returns true while
+// the path continues; when it returns false ps.L holds the path's radiance.
+template <int TRAV, bool COUNT, typename StackT>
+RT_HD bool path_step(const DevScene &sc, const f4 *slots, const f4 *nodes, const DevCamera &cam, PathState &ps,
+                     StackT *stack, int stack_stride, unsigned &n_rays, Cnt<COUNT> &cn) {
+    if (ps.depth <= 0) return false; // camera.h:141
+    n_rays++;
+    TraceHit h;
+    if constexpr (TRAV == TRAV_LINEAR)
+        h = trace_linear<COUNT>(sc, slots, sc.meta, ps.ray, 0.001f, RT_INF, cn);
+    else
+        h = trace_bvh<COUNT, StackT>(sc, slots, nodes, sc.meta, ps.ray, 0.001f, RT_INF, stack, stack_stride, cn);
+    if (h.slot < 0) { // camera.h:148-161
+        ps.L = ps.L + ps.beta * mk(cam.background[0], cam.background[1], cam.background[2]);
+        return false;
+    }
+    Surf s = surface_at(sc, slots, sc.meta, ps.ray, h);
+    ps.depth--;
+    return shade_hit<COUNT>(sc, cam, ps, s, cn);
+}
+
+} // namespace rtc

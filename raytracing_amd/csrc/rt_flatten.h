@@ -1,0 +1,469 @@
+// rt_flatten.h — host-only: turns an rt_scene_desc into the flat arrays the
+// kernels read (rt_core.h: primitive slots, per-slot meta, BVH nodes, wrapper ops).
+// No HIP calls here; rt_host.cpp uploads the result.
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rt_amd.h"
+#include "rt_core.h"
+
+namespace rtf {
+
+using rtc::f3;
+using rtc::f4;
+using rtc::i4;
+using rtc::mk;
+
+const int kLinearMaxPrims = 32;       // at most this many primitives: scan, no tree
+const int kMaxLdsBytes = 160 * 1024;  // LDS per CU on gfx950
+const int kMaxInnerDepth = RT_STACK_DEPTH - 2;
+
+// ---------------------------------------------------------------------------------------
+// wrapper ops on the host (same formulas as rt_core.h uses on the device)
+struct HostOp {
+    int type;
+    f3 p;
+    f4 a, b; // {sa ca sb cb} {sg cg 0 0}
+};
+
+HostOp make_op(const rt_xform_op &op) {
+    HostOp h;
+    h.type = op.type;
+    h.p = mk(op.p[0], op.p[1], op.p[2]);
+    h.a = f4{0.0f, 1.0f, 0.0f, 1.0f};
+    h.b = f4{0.0f, 1.0f, 0.0f, 0.0f};
+    const float pi = RT_PI;
+    if (op.type == RT_XF_ROTATE_Y) { // hittable.h:102-105
+        float radians = op.p[0] * pi / 180.0f;
+        h.a.z = sinf(radians);
+        h.a.w = cosf(radians);
+    } else if (op.type == RT_XF_ROTATE_XYZ) { // hittable.h:214-223
+        float ar = op.p[0] * pi / 180.0f, br = op.p[1] * pi / 180.0f, gr = op.p[2] * pi / 180.0f;
+        h.a.x = sinf(ar);
+        h.a.y = cosf(ar);
+        h.a.z = sinf(br);
+        h.a.w = cosf(br);
+        h.b.x = sinf(gr);
+        h.b.y = cosf(gr);
+    }
+    return h;
+}
+
+f3 op_point(const HostOp &h, f3 p) {
+    switch (h.type) {
+    case RT_XF_TRANSLATE: return p + h.p;
+    case RT_XF_ROTATE_Y: return rtc::rot_y_ccw(h.a, p);
+    case RT_XF_ROTATE_XYZ: return rtc::rot_xyz_ccw(h.a, h.b, p);
+    default: return p * h.p;
+    }
+}
+f3 op_vector(const HostOp &h, f3 v) {
+    switch (h.type) {
+    case RT_XF_TRANSLATE: return v;
+    case RT_XF_ROTATE_Y: return rtc::rot_y_ccw(h.a, v);
+    case RT_XF_ROTATE_XYZ: return rtc::rot_xyz_ccw(h.a, h.b, v);
+    default: return v * h.p;
+    }
+}
+
+// quad constants as the constructor derives them (quad.h:15-20)
+void quad_slot(f3 Q, f3 u, f3 v, f4 out[4]) {
+    f3 n = rtc::cross(u, v);
+    f3 normal = rtc::unit(n);
+    float D = rtc::dot(normal, Q);
+    f3 w = n / rtc::dot(n, n);
+    out[0] = f4{normal.x, normal.y, normal.z, D};
+    out[1] = f4{Q.x, Q.y, Q.z, w.x};
+    out[2] = f4{w.y, w.z, u.x, u.y};
+    out[3] = f4{u.z, v.x, v.y, v.z};
+}
+
+struct Box3 {
+    float lo[3], hi[3];
+    void reset() {
+        for (int k = 0; k < 3; k++) {
+            lo[k] = INFINITY;
+            hi[k] = -INFINITY;
+        }
+    }
+    void add(f3 p) {
+        const float c[3] = {p.x, p.y, p.z};
+        for (int k = 0; k < 3; k++) {
+            lo[k] = std::min(lo[k], c[k]);
+            hi[k] = std::max(hi[k], c[k]);
+        }
+    }
+    void add(const Box3 &b) {
+        for (int k = 0; k < 3; k++) {
+            lo[k] = std::min(lo[k], b.lo[k]);
+            hi[k] = std::max(hi[k], b.hi[k]);
+        }
+    }
+    float area() const {
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+// The exact primitive tests run in fp32 and can report a hit for a ray that misses
+// the ideal primitive by a hair (a sphere seen from distance L can be off by about
+// 2e-7 L^2 / r).  Culling must never drop such a hit, so boxes are grown by a small
+// fraction of their size plus a few ulps of their coordinates.
+void pad_box(Box3 &b) {
+    float ext = std::max(b.hi[0] - b.lo[0], std::max(b.hi[1] - b.lo[1], b.hi[2] - b.lo[2]));
+    float mag = 0.0f;
+    for (int k = 0; k < 3; k++) mag = std::max(mag, std::max(std::fabs(b.lo[k]), std::fabs(b.hi[k])));
+    float pad = 2e-3f * ext + 1e-5f * mag + 1e-30f;
+    for (int k = 0; k < 3; k++) {
+        b.lo[k] -= pad;
+        b.hi[k] += pad;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Binned-SAH BVH2 builder.  Leaves hold one primitive; a parent stores the boxes
+// of both children (one 64-byte fetch tests both).
+struct BvhOut {
+    std::vector<f4> nodes;       // 4 per node
+    std::vector<int> leaf_order; // slot -> input primitive index
+    int max_inner_depth = 0;
+};
+
+class BvhBuilder {
+  public:
+    BvhBuilder(const std::vector<Box3> &boxes, const std::vector<int> &types)
+        : boxes_(boxes), types_(types) {
+        size_t n = boxes.size();
+        idx_.resize(n);
+        cen_.resize(n * 3);
+        for (size_t i = 0; i < n; i++) {
+            idx_[i] = (int)i;
+            for (int k = 0; k < 3; k++) cen_[i * 3 + k] = 0.5f * (boxes[i].lo[k] + boxes[i].hi[k]);
+        }
+    }
+
+    BvhOut run() {
+        out_.nodes.reserve(idx_.size() * 4);
+        out_.leaf_order.reserve(idx_.size());
+        Box3 b;
+        build(0, (int)idx_.size(), 0, b);
+        return std::move(out_);
+    }
+
+  private:
+    static int ceil_log2(int n) {
+        int l = 0;
+        while ((1 << l) < n) l++;
+        return l;
+    }
+
+    // Builds the subtree over idx_[first, first+count) and returns its reference.
+    int build(int first, int count, int depth, Box3 &box) {
+        box.reset();
+        for (int i = first; i < first + count; i++) box.add(boxes_[idx_[i]]);
+        if (count == 1) {
+            int prim = idx_[first];
+            int slot = (int)out_.leaf_order.size();
+            out_.leaf_order.push_back(prim);
+            return ~(slot * 2 + (types_[prim] == RT_PRIM_QUAD ? 1 : 0));
+        }
+        out_.max_inner_depth = std::max(out_.max_inner_depth, depth);
+        int node = (int)(out_.nodes.size() / 4);
+        out_.nodes.resize(out_.nodes.size() + 4);
+
+        int mid = split_sah(first, count);
+        int nl = mid - first, nr = count - nl;
+        bool ok = nl > 0 && nr > 0 && depth + ceil_log2(nl) <= kMaxInnerDepth &&
+                  depth + ceil_log2(nr) <= kMaxInnerDepth;
+        if (!ok) mid = split_median(first, count);
+
+        Box3 b0, b1;
+        int r0 = build(first, mid - first, depth + 1, b0);
+        int r1 = build(mid, first + count - mid, depth + 1, b1);
+        f4 *n = &out_.nodes[(size_t)node * 4];
+        n[0] = f4{b0.lo[0], b0.lo[1], b0.lo[2], b0.hi[0]};
+        n[1] = f4{b0.hi[1], b0.hi[2], b1.lo[0], b1.lo[1]};
+        n[2] = f4{b1.lo[2], b1.hi[0], b1.hi[1], b1.hi[2]};
+        n[3] = f4{__builtin_bit_cast(float, r0), __builtin_bit_cast(float, r1), 0.0f, 0.0f};
+        return node;
+    }
+
+    int split_median(int first, int count) {
+        Box3 cb;
+        cb.reset();
+        for (int i = first; i < first + count; i++) {
+            const float *c = &cen_[(size_t)idx_[i] * 3];
+            cb.add(mk(c[0], c[1], c[2]));
+        }
+        int axis = 0;
+        for (int k = 1; k < 3; k++)
+            if (cb.hi[k] - cb.lo[k] > cb.hi[axis] - cb.lo[axis]) axis = k;
+        int mid = first + count / 2;
+        std::nth_element(idx_.begin() + first, idx_.begin() + mid, idx_.begin() + first + count,
+                         [&](int a, int b) { return cen_[(size_t)a * 3 + axis] < cen_[(size_t)b * 3 + axis]; });
+        return mid;
+    }
+
+    int split_sah(int first, int count) {
+        const int NB = 16;
+        Box3 cb;
+        cb.reset();
+        for (int i = first; i < first + count; i++) {
+            const float *c = &cen_[(size_t)idx_[i] * 3];
+            cb.add(mk(c[0], c[1], c[2]));
+        }
+        float best_cost = INFINITY;
+        int best_axis = -1, best_bin = -1;
+        for (int axis = 0; axis < 3; axis++) {
+            float lo = cb.lo[axis], ext = cb.hi[axis] - cb.lo[axis];
+            if (!(ext > 0.0f)) continue;
+            Box3 bb[NB];
+            int bc[NB];
+            for (int b = 0; b < NB; b++) {
+                bb[b].reset();
+                bc[b] = 0;
+            }
+            float scale = NB / ext;
+            for (int i = first; i < first + count; i++) {
+                int p = idx_[i];
+                int b = std::min(NB - 1, std::max(0, (int)((cen_[(size_t)p * 3 + axis] - lo) * scale)));
+                bb[b].add(boxes_[p]);
+                bc[b]++;
+            }
+            float right_area[NB];
+            int right_cnt[NB];
+            Box3 acc;
+            acc.reset();
+            int cnt = 0;
+            for (int b = NB - 1; b > 0; b--) {
+                acc.add(bb[b]);
+                cnt += bc[b];
+                right_area[b] = cnt ? acc.area() : 0.0f;
+                right_cnt[b] = cnt;
+            }
+            acc.reset();
+            cnt = 0;
+            for (int b = 0; b < NB - 1; b++) {
+                acc.add(bb[b]);
+                cnt += bc[b];
+                if (cnt == 0 || right_cnt[b + 1] == 0) continue;
+                float cost = acc.area() * cnt + right_area[b + 1] * right_cnt[b + 1];
+                if (cost < best_cost) {
+                    best_cost = cost;
+                    best_axis = axis;
+                    best_bin = b;
+                }
+            }
+        }
+        if (best_axis < 0) return first; // all centroids coincide: caller falls back to the median
+        float lo = cb.lo[best_axis], scale = NB / (cb.hi[best_axis] - cb.lo[best_axis]);
+        auto it = std::partition(idx_.begin() + first, idx_.begin() + first + count, [&](int p) {
+            int b = std::min(NB - 1, std::max(0, (int)((cen_[(size_t)p * 3 + best_axis] - lo) * scale)));
+            return b <= best_bin;
+        });
+        return (int)(it - idx_.begin());
+    }
+
+    const std::vector<Box3> &boxes_;
+    const std::vector<int> &types_;
+    std::vector<int> idx_;
+    std::vector<float> cen_;
+    BvhOut out_;
+};
+
+
+// Flat scene on the host.
+struct HostScene {
+    std::vector<f4> slots;       // n_prims * slot_f4
+    std::vector<i4> meta;        // per slot {type, material, chain, prim id}
+    std::vector<f4> nodes;       // 4 per BVH node (empty: linear scan)
+    std::vector<f4> xf;          // 3 per wrapper op, packed chain by chain
+    std::vector<int> chain_first; // n_chains + 1
+    int slot_f4 = 2;
+    int n_prims = 0, n_spheres = 0, n_quads = 0;
+    int n_nodes = 0, bvh_depth = 0;
+    bool linear = true;
+};
+
+// flags: RT_SCENE_FORCE_* (rt_amd.h).  The descriptor must already be validated.
+inline int flatten_scene(const rt_scene_desc *d, uint32_t flags, HostScene &out, std::string &err) {
+    const int n = d->n_prims;
+    bool linear = n <= kLinearMaxPrims;
+    if (flags & RT_SCENE_FORCE_BVH) linear = n < 2;
+    if (flags & RT_SCENE_FORCE_LINEAR) linear = true;
+
+    std::vector<HostOp> ops(d->n_xform_ops);
+    for (int i = 0; i < d->n_xform_ops; i++) ops[i] = make_op(d->xform_ops[i]);
+
+    bool any_quad = false;
+    for (int i = 0; i < n; i++) any_quad = any_quad || d->prims[i].type == RT_PRIM_QUAD;
+    const int slot_f4 = any_quad ? 4 : 2;
+
+    // per-primitive constants in input (test) order
+    std::vector<f4> geom((size_t)n * slot_f4, f4{0, 0, 0, 0});
+    std::vector<Box3> boxes(linear ? 0 : n);
+    std::vector<int> types(n);
+    for (int i = 0; i < n; i++) {
+        const rt_prim &p = d->prims[i];
+        types[i] = p.type;
+        f4 *g = &geom[(size_t)i * slot_f4];
+        const bool wrapped = p.xform >= 0;
+        int first = 0, last = 0;
+        if (wrapped) {
+            first = d->chains[p.xform].first_op;
+            last = first + d->chains[p.xform].n_ops;
+        }
+        if (p.type == RT_PRIM_SPHERE) {
+            f3 c1 = mk(p.a[0], p.a[1], p.a[2]);
+            f3 cv = (p.flags & RT_PRIM_FLAG_MOVING) ? mk(p.b[0], p.b[1], p.b[2]) : mk(0.0f, 0.0f, 0.0f);
+            float radius = p.c[0];
+            if (!linear && wrapped) {
+                // a translated / uniformly scaled sphere is still a sphere; anything else needs
+                // true instancing, which only the linear scan provides
+                for (int k = first; k < last; k++) {
+                    const HostOp &h = ops[k];
+                    if (h.type == RT_XF_TRANSLATE) {
+                        c1 = c1 + h.p;
+                    } else if (h.type == RT_XF_SCALE && h.p.x == h.p.y && h.p.y == h.p.z) {
+                        c1 = c1 * h.p;
+                        cv = cv * h.p;
+                        radius = radius * h.p.x;
+                    } else {
+                        err = "prim " + std::to_string(i) +
+                              ": rotated / non-uniformly scaled sphere inside a BVH scene";
+                        return RT_ERR_UNSUPPORTED;
+                    }
+                }
+            }
+            g[0] = f4{c1.x, c1.y, c1.z, radius};
+            g[1] = f4{cv.x, cv.y, cv.z, 0.0f};
+            if (!linear) {
+                Box3 &b = boxes[i];
+                b.reset();
+                f3 rv = mk(std::fabs(radius), std::fabs(radius), std::fabs(radius));
+                f3 c2 = c1 + cv; // ray times lie in [0,1): c1 + t*cv stays between c1 and c1 + cv
+                b.add(c1 - rv);
+                b.add(c1 + rv);
+                b.add(c2 - rv);
+                b.add(c2 + rv);
+                pad_box(b);
+            }
+        } else {
+            f3 Q = mk(p.a[0], p.a[1], p.a[2]), u = mk(p.b[0], p.b[1], p.b[2]), v = mk(p.c[0], p.c[1], p.c[2]);
+            if (!linear && wrapped) { // fold the wrappers into the quad: an affine image of a
+                for (int k = first; k < last; k++) { // parallelogram is a parallelogram
+                    Q = op_point(ops[k], Q);
+                    u = op_vector(ops[k], u);
+                    v = op_vector(ops[k], v);
+                }
+            }
+            quad_slot(Q, u, v, g);
+            if (!linear) {
+                Box3 &b = boxes[i];
+                b.reset();
+                b.add(Q);
+                b.add(Q + u);
+                b.add(Q + v);
+                b.add(Q + u + v);
+                pad_box(b);
+            }
+        }
+    }
+
+    out.n_prims = n;
+    out.slot_f4 = slot_f4;
+    out.linear = linear;
+    for (int i = 0; i < n; i++) (types[i] == RT_PRIM_SPHERE ? out.n_spheres : out.n_quads)++;
+
+    std::vector<f4> &slots = out.slots;
+    std::vector<i4> &meta = out.meta;
+    std::vector<f4> &nodes = out.nodes;
+    meta.resize(n);
+    if (linear) {
+        slots = geom;
+        for (int i = 0; i < n; i++) meta[i] = i4{types[i], d->prims[i].material, d->prims[i].xform, i};
+    } else {
+        BvhBuilder builder(boxes, types);
+        BvhOut bo = builder.run();
+        nodes = std::move(bo.nodes);
+        slots.resize((size_t)n * slot_f4);
+        for (int sl = 0; sl < n; sl++) {
+            int pi = bo.leaf_order[sl];
+            memcpy(&slots[(size_t)sl * slot_f4], &geom[(size_t)pi * slot_f4], sizeof(f4) * slot_f4);
+            meta[sl] = i4{types[pi], d->prims[pi].material, -1, pi};
+        }
+        out.n_nodes = (int)(nodes.size() / 4);
+        out.bvh_depth = bo.max_inner_depth + 1;
+    }
+
+    // wrapper ops / chains (only the linear scan applies them at run time)
+    std::vector<f4> xf((size_t)d->n_xform_ops * 3);
+    for (int i = 0; i < d->n_xform_ops; i++) {
+        xf[3 * i] = f4{__builtin_bit_cast(float, ops[i].type), ops[i].p.x, ops[i].p.y, ops[i].p.z};
+        xf[3 * i + 1] = ops[i].a;
+        xf[3 * i + 2] = ops[i].b;
+    }
+    // chains are re-packed so that chain c covers ops [chain_first[c], chain_first[c+1])
+    std::vector<f4> &xf_packed = out.xf;
+    std::vector<int> &chain_first = out.chain_first;
+    chain_first.assign(d->n_chains + 1, 0);
+    for (int c = 0; c < d->n_chains; c++) {
+        chain_first[c] = (int)(xf_packed.size() / 3);
+        for (int k = 0; k < d->chains[c].n_ops; k++)
+            for (int w = 0; w < 3; w++) xf_packed.push_back(xf[3 * (d->chains[c].first_op + k) + w]);
+    }
+    chain_first[d->n_chains] = (int)(xf_packed.size() / 3);
+
+    return RT_OK;
+}
+
+// camera::initialize (camera.h:76-111) in the reference's fp32 operation order.
+inline void camera_frame(const rt_camera_desc *c, rt_camera_frame *f) {
+    memset(f, 0, sizeof(*f));
+    f->image_width = c->image_width;
+    int image_height = int(c->image_width / c->aspect_ratio);
+    image_height = (image_height < 1) ? 1 : image_height;
+    f->image_height = image_height;
+    f->pixel_samples_scale = 1.0f / c->samples_per_pixel;
+    f3 lookfrom = mk(c->lookfrom[0], c->lookfrom[1], c->lookfrom[2]);
+    f3 lookat = mk(c->lookat[0], c->lookat[1], c->lookat[2]);
+    f3 vup = mk(c->vup[0], c->vup[1], c->vup[2]);
+    f3 center = lookfrom;
+    float theta = c->vfov * RT_PI / 180.0f;
+    float h = tanf(theta / 2.0f);
+    float viewport_height = 2.0f * h * c->focus_dist;
+    float viewport_width = viewport_height * (float(c->image_width) / image_height);
+    f3 w = rtc::unit(lookfrom - lookat);
+    f3 u = rtc::unit(rtc::cross(vup, w));
+    f3 v = rtc::cross(w, u);
+    f3 viewport_u = viewport_width * u;
+    f3 viewport_v = viewport_height * -v;
+    f3 pdu = viewport_u / float(c->image_width);
+    f3 pdv = viewport_v / float(image_height);
+    f3 upper_left = center - (c->focus_dist * w) - viewport_u / 2.0f - viewport_v / 2.0f;
+    f3 p00 = upper_left + 0.5f * (pdu + pdv);
+    float defocus_radius = c->focus_dist * tanf((c->defocus_angle / 2.0f) * RT_PI / 180.0f);
+    f3 ddu = u * defocus_radius;
+    f3 ddv = v * defocus_radius;
+    auto put = [](float *dst, f3 s) {
+        dst[0] = s.x;
+        dst[1] = s.y;
+        dst[2] = s.z;
+    };
+    put(f->center, center);
+    put(f->pixel00_loc, p00);
+    put(f->pixel_delta_u, pdu);
+    put(f->pixel_delta_v, pdv);
+    put(f->u, u);
+    put(f->v, v);
+    put(f->w, w);
+    put(f->defocus_disk_u, ddu);
+    put(f->defocus_disk_v, ddv);
+}
+
+} // namespace rtf

@@ -1,0 +1,532 @@
+// rt_host.cpp — host half of librt_amd.so: the C ABI of include/rt_amd.h.
+//
+// Flattens an rt_scene_desc into the device layout of rt_core.h (primitive
+// slots, BVH nodes, wrapper ops, material / texture tables), uploads it once,
+// and enqueues the kernels of rt_kernels.hip.  There is no CPU rendering path
+// in this library: without a HIP device every compute entry point fails.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rt_amd.h"
+#include "rt_core.h"
+#include "rt_flatten.h"
+#include "rt_launch.h"
+#include "rt_scene_io.h"
+
+using rtc::f3;
+using rtc::f4;
+using rtc::i4;
+using rtc::mk;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define RT_HIP(call)                                                                               \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) return fail(RT_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_));     \
+    } while (0)
+
+const int kMaxLdsBytes = 160 * 1024; // LDS per CU on gfx950
+
+} // namespace
+
+// ---------------------------------------------------------------------------------------
+struct rt_scene {
+    int device = 0;
+    rtc::DevScene dev;
+    rt_scene_info info;
+    std::vector<void *> allocs;
+    // render scratch (owned by the scene, grown on demand)
+    f4 *stage = nullptr;
+    size_t stage_bytes = 0;
+    unsigned long long *d_words = nullptr; // [0] pool counter, [1] ray counter
+    rtc::Counters *d_counters = nullptr;
+    int n_cu = 256;
+    // optional per-launch timing of the render kernel
+    bool profiling = false;
+    std::vector<hipEvent_t> prof_events; // pairs
+};
+
+namespace {
+
+template <class T> int upload(rt_scene *s, const std::vector<T> &v, const T **out) {
+    size_t bytes = std::max<size_t>(v.size() * sizeof(T), 16);
+    void *p = nullptr;
+    RT_HIP(hipMalloc(&p, bytes));
+    s->allocs.push_back(p);
+    if (!v.empty()) RT_HIP(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    s->info.device_bytes += bytes;
+    *out = (const T *)p;
+    return RT_OK;
+}
+
+int validate(const rt_scene_desc *d) {
+    if (!d) return fail(RT_ERR_ARG, "scene descriptor is null");
+    if (d->abi_version != RT_AMD_ABI_VERSION)
+        return fail(RT_ERR_ARG, "descriptor abi_version %u, library %d", d->abi_version, RT_AMD_ABI_VERSION);
+    if (d->n_prims < 0 || (d->n_prims > 0 && !d->prims)) return fail(RT_ERR_ARG, "bad prims array");
+    if (d->n_prims >= (1 << 29)) return fail(RT_ERR_ARG, "too many primitives");
+    for (int i = 0; i < d->n_prims; i++) {
+        const rt_prim &p = d->prims[i];
+        if (p.type != RT_PRIM_SPHERE && p.type != RT_PRIM_QUAD)
+            return fail(RT_ERR_ARG, "prim %d: unknown type %d", i, p.type);
+        if (p.material < 0 || p.material >= d->n_materials)
+            return fail(RT_ERR_ARG, "prim %d: material %d out of range", i, p.material);
+        if (p.xform < -1 || p.xform >= d->n_chains) return fail(RT_ERR_ARG, "prim %d: chain out of range", i);
+    }
+    for (int i = 0; i < d->n_materials; i++) {
+        const rt_material &m = d->materials[i];
+        if (m.type < RT_MAT_LAMBERTIAN || m.type > RT_MAT_DIFFUSE_LIGHT)
+            return fail(RT_ERR_ARG, "material %d: unknown type %d", i, m.type);
+        if ((m.type == RT_MAT_LAMBERTIAN || m.type == RT_MAT_DIFFUSE_LIGHT) &&
+            (m.texture < 0 || m.texture >= d->n_textures))
+            return fail(RT_ERR_ARG, "material %d: texture out of range", i);
+    }
+    for (int i = 0; i < d->n_textures; i++) {
+        const rt_texture &t = d->textures[i];
+        if (t.type < RT_TEX_SOLID || t.type > RT_TEX_NOISE)
+            return fail(RT_ERR_ARG, "texture %d: unknown type %d", i, t.type);
+        if (t.type == RT_TEX_CHECKER &&
+            (t.even < 0 || t.even >= d->n_textures || t.odd < 0 || t.odd >= d->n_textures))
+            return fail(RT_ERR_ARG, "texture %d: checker child out of range", i);
+        if (t.type == RT_TEX_NOISE && (t.perlin < 0 || t.perlin >= d->n_perlins))
+            return fail(RT_ERR_ARG, "texture %d: perlin table out of range", i);
+        if (t.type == RT_TEX_IMAGE && t.image >= d->n_images)
+            return fail(RT_ERR_ARG, "texture %d: image out of range", i);
+    }
+    for (int i = 0; i < d->n_images; i++) {
+        const rt_image &im = d->images[i];
+        if (im.width <= 0 || im.height <= 0 ||
+            im.offset + (uint64_t)im.width * im.height * 3 > d->n_texel_bytes)
+            return fail(RT_ERR_ARG, "image %d: texels out of range", i);
+    }
+    for (int i = 0; i < d->n_chains; i++) {
+        const rt_xform_chain &c = d->chains[i];
+        if (c.first_op < 0 || c.n_ops < 0 || c.first_op + c.n_ops > d->n_xform_ops)
+            return fail(RT_ERR_ARG, "chain %d: ops out of range", i);
+    }
+    return RT_OK;
+}
+
+int set_device(int device) {
+    RT_HIP(hipSetDevice(device));
+    return RT_OK;
+}
+
+} // namespace
+
+// =========================================================================================
+extern "C" {
+
+const char *rt_last_error(void) { return g_err.c_str(); }
+int rt_abi_version(void) { return RT_AMD_ABI_VERSION; }
+
+int rt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int rt_camera_initialize(const rt_camera_desc *c, rt_camera_frame *f) { // camera.h:76-111
+    if (!c || !f) return fail(RT_ERR_ARG, "null camera");
+    if (c->image_width < 1 || c->samples_per_pixel < 1 || !(c->aspect_ratio > 0.0f))
+        return fail(RT_ERR_ARG, "camera: image_width, samples_per_pixel and aspect_ratio must be positive");
+    rtf::camera_frame(c, f);
+    return RT_OK;
+}
+
+int rt_scene_destroy(rt_scene *s) {
+    if (!s) return RT_OK;
+    hipSetDevice(s->device);
+    for (void *p : s->allocs) hipFree(p);
+    if (s->stage) hipFree(s->stage);
+    for (hipEvent_t e : s->prof_events) hipEventDestroy(e);
+    delete s;
+    return RT_OK;
+}
+
+int rt_scene_create(const rt_scene_desc *d, int device, uint32_t flags, rt_scene **out) {
+    if (!out) return fail(RT_ERR_ARG, "out is null");
+    *out = nullptr;
+    int rc = validate(d);
+    if (rc != RT_OK) return rc;
+    int n_dev = rt_device_count();
+    if (n_dev <= 0) return fail(RT_ERR_HIP, "no HIP device available (this library has no CPU path)");
+    if (device < 0 || device >= n_dev) return fail(RT_ERR_ARG, "device %d out of range (%d visible)", device, n_dev);
+    rc = set_device(device);
+    if (rc != RT_OK) return rc;
+
+    rtf::HostScene hs;
+    {
+        std::string err;
+        rc = rtf::flatten_scene(d, flags, hs, err);
+        if (rc != RT_OK) return fail(rc, "%s", err.c_str());
+    }
+    const int n = hs.n_prims;
+    const bool linear = hs.linear;
+    const int slot_f4 = hs.slot_f4;
+    const std::vector<f4> &slots = hs.slots, &nodes = hs.nodes, &xf_packed = hs.xf;
+    const std::vector<i4> &meta = hs.meta;
+    const std::vector<int> &chain_first = hs.chain_first;
+
+    rt_scene *s = new rt_scene();
+    s->device = device;
+    memset(&s->info, 0, sizeof(s->info));
+    memset(&s->dev, 0, sizeof(s->dev));
+    s->info.n_prims = n;
+    s->info.n_spheres = hs.n_spheres;
+    s->info.n_quads = hs.n_quads;
+    s->info.n_nodes = hs.n_nodes;
+    s->info.bvh_depth = hs.bvh_depth;
+
+    std::vector<rt_material> mats(d->materials, d->materials + d->n_materials);
+    std::vector<rt_texture> texs(d->textures, d->textures + d->n_textures);
+    std::vector<rt_perlin> perl(d->perlins, d->perlins + d->n_perlins);
+    std::vector<rt_image> imgs(d->images, d->images + d->n_images);
+    std::vector<uint8_t> texels(d->texels, d->texels + d->n_texel_bytes);
+
+    rtc::DevScene &dv = s->dev;
+    rc = upload(s, slots, &dv.slots);
+    if (rc == RT_OK) rc = upload(s, meta, &dv.meta);
+    if (rc == RT_OK) rc = upload(s, nodes, &dv.nodes);
+    if (rc == RT_OK) rc = upload(s, xf_packed, &dv.xf);
+    if (rc == RT_OK) rc = upload(s, chain_first, &dv.chain_first);
+    if (rc == RT_OK) rc = upload(s, mats, &dv.materials);
+    if (rc == RT_OK) rc = upload(s, texs, &dv.textures);
+    if (rc == RT_OK) rc = upload(s, perl, &dv.perlins);
+    if (rc == RT_OK) rc = upload(s, imgs, &dv.images);
+    if (rc == RT_OK) rc = upload(s, texels, &dv.texels);
+    std::vector<unsigned long long> words(4, 0ull);
+    const unsigned long long *dw = nullptr;
+    if (rc == RT_OK) rc = upload(s, words, &dw);
+    std::vector<rtc::Counters> cnt(1);
+    memset(cnt.data(), 0, sizeof(rtc::Counters));
+    const rtc::Counters *dc = nullptr;
+    if (rc == RT_OK) rc = upload(s, cnt, &dc);
+    if (rc != RT_OK) {
+        std::string keep = g_err;
+        rt_scene_destroy(s);
+        g_err = keep;
+        return rc;
+    }
+    s->d_words = const_cast<unsigned long long *>(dw);
+    s->d_counters = const_cast<rtc::Counters *>(dc);
+    dv.n_slots = n;
+    dv.n_nodes = (int)(nodes.size() / 4);
+    dv.slot_f4 = slot_f4;
+    dv.traversal = linear ? rtc::TRAV_LINEAR : rtc::TRAV_BVH;
+    dv.n_chains = d->n_chains;
+    dv.n_xf_ops = (int)(xf_packed.size() / 3);
+
+    int n_cu = 0;
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n_cu > 0)
+        s->n_cu = n_cu;
+    hipError_t e = rtl::set_mega_lds_limit(kMaxLdsBytes);
+    if (e != hipSuccess) {
+        rt_scene_destroy(s);
+        return fail(RT_ERR_HIP, "cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+    }
+
+    // Does the geometry fit LDS next to the traversal stacks?
+    size_t scene_bytes = ((size_t)n * slot_f4 + nodes.size()) * sizeof(f4);
+    bool short_ok = dv.n_nodes < 32768 && n < 16384;
+    s->info.lds_resident = 0;
+    if (!(flags & RT_SCENE_FORCE_GLOBAL) && short_ok) {
+        size_t stack = linear ? 0 : (size_t)(s->info.bvh_depth + 1) * 256 * sizeof(short);
+        if (scene_bytes + stack <= (size_t)kMaxLdsBytes) s->info.lds_resident = 1;
+    }
+    *out = s;
+    return RT_OK;
+}
+
+int rt_scene_get_info(const rt_scene *s, rt_scene_info *out) {
+    if (!s || !out) return fail(RT_ERR_ARG, "null argument");
+    *out = s->info;
+    return RT_OK;
+}
+
+} // extern "C"
+
+namespace {
+
+// Workgroup shape of the persistent render kernel for this scene.
+LaunchGeom choose_geom(const rt_scene *s) {
+    LaunchGeom lg;
+    const rtc::DevScene &dv = s->dev;
+    const bool bvh = dv.traversal == rtc::TRAV_BVH;
+    const int levels = s->info.bvh_depth + 1;
+    size_t scene_bytes = ((size_t)dv.n_slots * dv.slot_f4 + (size_t)dv.n_nodes * 4) * sizeof(f4);
+    lg.lds_scene = s->info.lds_resident != 0;
+    int block = 1024;
+    const char *env_block = getenv("RT_AMD_BLOCK");
+    if (env_block) block = std::max(64, std::min(1024, atoi(env_block) / 64 * 64));
+    for (;; block /= 2) {
+        size_t stack = bvh ? (size_t)levels * block * (lg.lds_scene ? sizeof(short) : sizeof(int)) : 0;
+        size_t total = (lg.lds_scene ? scene_bytes : 0) + stack;
+        if (total <= (size_t)kMaxLdsBytes || block <= 64) {
+            lg.block = block;
+            lg.lds_bytes = (int)std::max<size_t>(total, 16);
+            break;
+        }
+    }
+    int per_cu_lds = kMaxLdsBytes / std::max(lg.lds_bytes, 1);
+    int per_cu_waves = 2048 / lg.block; // 32 waves per CU
+    int per_cu = std::max(1, std::min(per_cu_lds, per_cu_waves));
+    const char *env_mult = getenv("RT_AMD_BLOCKS_PER_CU");
+    if (env_mult) per_cu = std::max(1, atoi(env_mult));
+    lg.grid = s->n_cu * per_cu;
+    return lg;
+}
+
+size_t stage_budget_bytes() {
+    const char *e = getenv("RT_AMD_STAGE_MB");
+    size_t mb = e ? (size_t)atoll(e) : 512;
+    return std::max<size_t>(mb, 1) << 20;
+}
+
+} // namespace
+
+extern "C" {
+
+int rt_render_device(rt_scene *s, const rt_camera_desc *cam, const rt_render_opts *opts, float *d_accum,
+                     void *stream_v, rt_render_stats *stats) {
+    if (!s || !cam || !opts || !d_accum) return fail(RT_ERR_ARG, "null argument");
+    if (opts->sample_count < 0 || opts->sample_begin < 0) return fail(RT_ERR_ARG, "negative sample range");
+    if (opts->mode != RT_MODE_MEGAKERNEL) return fail(RT_ERR_UNSUPPORTED, "render mode %d not available", opts->mode);
+    if (cam->max_depth < 0) return fail(RT_ERR_ARG, "negative max_depth");
+    int rc = set_device(s->device);
+    if (rc != RT_OK) return rc;
+    hipStream_t stream = (hipStream_t)stream_v;
+
+    rtc::DevCamera dc;
+    rc = rt_camera_initialize(cam, &dc.f);
+    if (rc != RT_OK) return rc;
+    for (int k = 0; k < 3; k++) dc.background[k] = cam->background[k];
+    dc.defocus_angle = cam->defocus_angle;
+    dc.max_depth = cam->max_depth;
+
+    const int W = dc.f.image_width, H = dc.f.image_height;
+    const long long n_pixels_ll = (long long)W * H;
+    if (n_pixels_ll > (1ll << 30)) return fail(RT_ERR_ARG, "image too large");
+    const int n_pixels = (int)n_pixels_ll;
+
+    if (stats) {
+        memset(stats, 0, sizeof(*stats));
+    }
+    if (opts->sample_count == 0) return RT_OK;
+
+    // samples per launch: the per-path record buffer is bounded
+    size_t per_sample = (size_t)n_pixels * sizeof(f4);
+    int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)opts->sample_count, stage_budget_bytes() / per_sample));
+    size_t need = per_sample * chunk;
+    if (need > s->stage_bytes) {
+        if (s->stage) RT_HIP(hipFree(s->stage));
+        s->stage = nullptr;
+        s->stage_bytes = 0;
+        RT_HIP(hipMalloc((void **)&s->stage, need));
+        s->stage_bytes = need;
+    }
+
+    const bool count = (opts->flags & RT_RENDER_COUNTERS) != 0 && stats != nullptr;
+    LaunchGeom lg = choose_geom(s);
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (stats) {
+        RT_HIP(hipEventCreate(&ev0));
+        RT_HIP(hipEventCreate(&ev1));
+        RT_HIP(hipMemsetAsync(s->d_words + 1, 0, sizeof(unsigned long long), stream));
+        if (count) RT_HIP(hipMemsetAsync(s->d_counters, 0, sizeof(rtc::Counters), stream));
+    }
+    float mega_ms = 0.0f;
+    for (int done = 0; done < opts->sample_count; done += chunk) {
+        int sc_n = std::min(chunk, opts->sample_count - done);
+        RenderParams rp;
+        rp.width = W;
+        rp.height = H;
+        rp.n_pixels = n_pixels;
+        rp.sample_begin = opts->sample_begin + done;
+        rp.sample_count = sc_n;
+        rp.seed = opts->seed;
+        rp.n_paths = (unsigned long long)((n_pixels + 63) / 64) * 64ull * (unsigned long long)sc_n;
+        rp.stage = s->stage;
+        rp.next_path = s->d_words;
+        rp.counters = count ? s->d_counters : nullptr;
+        RT_HIP(hipMemsetAsync(s->d_words, 0, sizeof(unsigned long long), stream));
+        hipEvent_t p0 = nullptr, p1 = nullptr;
+        if (s->profiling) {
+            RT_HIP(hipEventCreate(&p0));
+            RT_HIP(hipEventCreate(&p1));
+            RT_HIP(hipEventRecord(p0, stream));
+        }
+        if (stats) RT_HIP(hipEventRecord(ev0, stream));
+        RT_HIP(rtl::launch_mega(s->dev, dc, rp, lg, stream));
+        if (stats) RT_HIP(hipEventRecord(ev1, stream));
+        if (s->profiling) {
+            RT_HIP(hipEventRecord(p1, stream));
+            s->prof_events.push_back(p0);
+            s->prof_events.push_back(p1);
+        }
+        RT_HIP(rtl::launch_reduce(s->stage, n_pixels, sc_n, d_accum, s->d_words + 1, stream));
+        if (stats) {
+            RT_HIP(hipEventSynchronize(ev1));
+            float ms = 0.0f;
+            RT_HIP(hipEventElapsedTime(&ms, ev0, ev1));
+            mega_ms += ms;
+        }
+    }
+    if (stats) {
+        RT_HIP(hipStreamSynchronize(stream));
+        hipEventDestroy(ev0);
+        hipEventDestroy(ev1);
+        unsigned long long rays = 0;
+        RT_HIP(hipMemcpy(&rays, s->d_words + 1, sizeof(rays), hipMemcpyDeviceToHost));
+        stats->paths = (uint64_t)n_pixels * (uint64_t)opts->sample_count;
+        stats->rays = rays;
+        stats->kernel_ms = mega_ms;
+        if (count) {
+            rtc::Counters c;
+            RT_HIP(hipMemcpy(&c, s->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+            stats->box_tests = c.box_tests;
+            stats->sphere_tests = c.sphere_tests;
+            stats->sphere_hits = c.sphere_hits;
+            stats->quad_tests = c.quad_tests;
+            for (int k = 0; k < 4; k++) stats->shades[k] = c.shades[k];
+            stats->noise_evals = c.noise_evals;
+            stats->image_evals = c.image_evals;
+            stats->checker_evals = c.checker_evals;
+        }
+    }
+    return RT_OK;
+}
+
+int rt_render(rt_scene *s, const rt_camera_desc *cam, const rt_render_opts *opts, float *accum_host,
+              rt_render_stats *stats) {
+    if (!s || !cam || !opts || !accum_host) return fail(RT_ERR_ARG, "null argument");
+    int rc = set_device(s->device);
+    if (rc != RT_OK) return rc;
+    rt_camera_frame f;
+    rc = rt_camera_initialize(cam, &f);
+    if (rc != RT_OK) return rc;
+    size_t bytes = (size_t)f.image_width * f.image_height * 3 * sizeof(float);
+    float *d_accum = nullptr;
+    RT_HIP(hipMalloc((void **)&d_accum, bytes));
+    hipError_t e = hipMemcpy(d_accum, accum_host, bytes, hipMemcpyHostToDevice);
+    rt_render_stats local;
+    if (e == hipSuccess) {
+        rc = rt_render_device(s, cam, opts, d_accum, nullptr, stats ? stats : &local);
+        if (rc == RT_OK) e = hipMemcpy(accum_host, d_accum, bytes, hipMemcpyDeviceToHost);
+    }
+    hipFree(d_accum);
+    if (rc != RT_OK) return rc;
+    if (e != hipSuccess) return fail(RT_ERR_HIP, "accumulation buffer copy: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_trace_batch_device(rt_scene *s, const rt_ray *d_rays, int64_t n, float tmin, float tmax, rt_hit *d_hits,
+                          void *stream) {
+    if (!s || n < 0 || (n > 0 && (!d_rays || !d_hits))) return fail(RT_ERR_ARG, "bad argument");
+    if (n == 0) return RT_OK;
+    int rc = set_device(s->device);
+    if (rc != RT_OK) return rc;
+    if (s->dev.traversal == rtc::TRAV_BVH && s->info.bvh_depth + 1 > RT_STACK_DEPTH)
+        return fail(RT_ERR_UNSUPPORTED, "tree deeper than the traversal stack");
+    RT_HIP(rtl::launch_trace(s->dev, d_rays, n, tmin, tmax, d_hits, (hipStream_t)stream));
+    return RT_OK;
+}
+
+int rt_trace_batch(rt_scene *s, const rt_ray *rays, int64_t n, float tmin, float tmax, rt_hit *hits) {
+    if (!s || n < 0 || (n > 0 && (!rays || !hits))) return fail(RT_ERR_ARG, "bad argument");
+    if (n == 0) return RT_OK;
+    int rc = set_device(s->device);
+    if (rc != RT_OK) return rc;
+    rt_ray *d_rays = nullptr;
+    rt_hit *d_hits = nullptr;
+    RT_HIP(hipMalloc((void **)&d_rays, sizeof(rt_ray) * n));
+    hipError_t e = hipMalloc((void **)&d_hits, sizeof(rt_hit) * n);
+    if (e == hipSuccess) e = hipMemcpy(d_rays, rays, sizeof(rt_ray) * n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        rc = rt_trace_batch_device(s, d_rays, n, tmin, tmax, d_hits, nullptr);
+        if (rc == RT_OK) e = hipDeviceSynchronize();
+        if (rc == RT_OK && e == hipSuccess) e = hipMemcpy(hits, d_hits, sizeof(rt_hit) * n, hipMemcpyDeviceToHost);
+    }
+    hipFree(d_rays);
+    if (d_hits) hipFree(d_hits);
+    if (rc != RT_OK) return rc;
+    if (e != hipSuccess) return fail(RT_ERR_HIP, "trace batch: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
+// write_color (color.h:17-32): sqrt gamma, clamp to [0, 0.999], 256 * c truncated.
+int rt_tonemap_u8(const float *accum, int64_t n_pixels, float scale, uint8_t *rgb8) {
+    if (n_pixels < 0 || (n_pixels > 0 && (!accum || !rgb8))) return fail(RT_ERR_ARG, "bad argument");
+    for (int64_t i = 0; i < n_pixels * 3; i++) {
+        float c = scale * accum[i];
+        float g = c > 0.0f ? sqrtf(c) : 0.0f;
+        g = g < 0.000f ? 0.000f : (g > 0.999f ? 0.999f : g);
+        rgb8[i] = (uint8_t) int(256 * g);
+    }
+    return RT_OK;
+}
+
+// Per-launch timing of the render kernel between begin and end (HIP events on the
+// stream the launches go to).  end returns the summed time and the launch count.
+int rt_profile_begin(rt_scene *s) {
+    if (!s) return fail(RT_ERR_ARG, "null scene");
+    for (hipEvent_t e : s->prof_events) hipEventDestroy(e);
+    s->prof_events.clear();
+    s->profiling = true;
+    return RT_OK;
+}
+int rt_profile_end(rt_scene *s, double *total_ms, int *n_launches) {
+    if (!s) return fail(RT_ERR_ARG, "null scene");
+    s->profiling = false;
+    double total = 0.0;
+    int n = 0;
+    for (size_t i = 0; i + 1 < s->prof_events.size(); i += 2) {
+        RT_HIP(hipEventSynchronize(s->prof_events[i + 1]));
+        float ms = 0.0f;
+        RT_HIP(hipEventElapsedTime(&ms, s->prof_events[i], s->prof_events[i + 1]));
+        total += ms;
+        n++;
+    }
+    for (hipEvent_t e : s->prof_events) hipEventDestroy(e);
+    s->prof_events.clear();
+    if (total_ms) *total_ms = total;
+    if (n_launches) *n_launches = n;
+    return RT_OK;
+}
+
+int rt_scene_file_save(const rt_scene_desc *desc, const char *path) {
+    if (!desc || !path) return fail(RT_ERR_ARG, "null argument");
+    int rc = rtio::save(desc, path);
+    if (rc != RT_OK) return fail(rc, "cannot write %s", path);
+    return RT_OK;
+}
+int rt_scene_file_load(const char *path, rt_scene_desc **out) {
+    if (!path || !out) return fail(RT_ERR_ARG, "null argument");
+    *out = rtio::load(path);
+    if (!*out) return fail(RT_ERR_IO, "cannot read %s", path);
+    return RT_OK;
+}
+void rt_scene_file_free(rt_scene_desc *desc) { free(desc); }
+
+} // extern "C"

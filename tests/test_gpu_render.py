@@ -1,0 +1,140 @@
+"""GPU parity of the render entry point (rt_render through the C ABI).
+
+Three bars:
+ 1. same random numbers, same integrator: the oracle run with the counter-based sampler
+    traces the same paths, so the fp32 radiance sums agree pixel for pixel except where a
+    device transcendental (sincospi, sinf, acosf, x^5) rounds differently and a path forks;
+ 2. converged images reach PSNR >= 40 dB on the 8-bit write_color image against the
+    reference's own converged render (tests/golden/<scene>.ref.png);
+ 3. size-independent properties: sample ranges add up, the image does not depend on how the
+    samples are split over calls, ray counts are reproducible."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from raytracing_amd import abi
+from tests import oracle_lib as O
+from tests.conftest import GOLDEN, SCENES, load_scene
+
+pytestmark = pytest.mark.gpu
+
+# GPU samples per pixel used against each converged reference image
+PSNR_SPP = {"bouncing_spheres": 4096, "checkered_spheres": 4096, "earth": 2048,
+            "perlin_spheres": 4096, "quads": 4096, "simple_light": 32768, "cornell_box": 65536}
+
+
+def _binding():
+    from raytracing_amd import binding
+    return binding
+
+
+@pytest.mark.parametrize("scene", SCENES)
+def test_render_matches_oracle_path_for_path(scene):
+    B = _binding()
+    arrays, cam, _ = load_scene(scene)
+    cam.image_width = 160 if scene != "cornell_box" else 120
+    spp = 4
+    sc = B.Scene(arrays)
+    acc, st = sc.render(cam, spp, seed=3)
+    osc = O.OracleScene(arrays)
+    ref, ost = osc.render(cam, spp, sampler=O.SAMPLER_CB, trace_mode=O.TRACE_REFERENCE, seed=3,
+                          n_threads=8)
+    assert st.paths == ost.paths
+    # ray counts: forked paths (see below) change the count; independent renders of this size
+    # differ by about 0.6 % (seed to seed), same-seed GPU vs oracle must stay well inside that
+    assert abs(int(st.rays) - int(ost.rays)) <= 6e-3 * ost.rays
+    diff = np.abs(acc - ref)
+    tol = 1e-4 * np.maximum(1.0, np.abs(ref))
+    frac_bad = float((diff > tol).any(axis=2).mean())
+    print(f"{scene}: rays gpu {st.rays} oracle {ost.rays}, pixels forked {frac_bad:.4f}, "
+          f"mean gpu {acc.mean():.5f} oracle {ref.mean():.5f}")
+    # noise-textured and glass scenes fork more often (sinf / sincospi ulps), still rare
+    assert frac_bad < 0.02, f"{frac_bad:.4f} of the pixels differ from the oracle"
+    assert abs(acc.mean() - ref.mean()) <= 2e-3 * max(ref.mean(), 1e-3)
+    sc.close()
+
+
+@pytest.mark.parametrize("scene", SCENES)
+def test_converged_image_psnr(scene):
+    png = os.path.join(GOLDEN, scene + ".ref.png")
+    if not os.path.exists(png):
+        pytest.skip("no converged reference image committed for this scene")
+    from PIL import Image
+    B = _binding()
+    arrays, cam, _ = load_scene(scene)
+    ref_u8 = np.asarray(Image.open(png).convert("RGB"))
+    spp = PSNR_SPP[scene]
+    sc = B.Scene(arrays)
+    acc, st = sc.render(cam, spp, seed=11)
+    img = B.tonemap_u8(acc, 1.0 / spp)
+    psnr = O.psnr_u8(img, ref_u8)
+    with open(os.path.join(GOLDEN, scene + ".ref.json")) as f:
+        meta = json.load(f)
+    mean = acc.reshape(-1, 3).mean(0) / spp
+    assert np.allclose(mean, meta["mean_linear_rgb"], rtol=0.02, atol=2e-3)
+    assert psnr >= 40.0, f"PSNR {psnr:.2f} dB"
+    sc.close()
+
+
+def test_sample_ranges_add_up_and_split_invariance():
+    B = _binding()
+    arrays, cam, _ = load_scene("bouncing_spheres")
+    cam.image_width = 200
+    sc = B.Scene(arrays)
+    whole, st = sc.render(cam, 16, seed=5)
+    a, st_a = sc.render(cam, 6, sample_begin=0, seed=5)
+    b, st_b = sc.render(cam, 10, sample_begin=6, seed=5)
+    assert st_a.rays + st_b.rays == st.rays
+    assert np.allclose(a + b, whole, rtol=1e-5, atol=1e-6)
+    # accumulate in place: second call adds to the first
+    acc2, _ = sc.render(cam, 6, sample_begin=0, seed=5)
+    acc2, _ = sc.render(cam, 10, sample_begin=6, seed=5, accum=acc2)
+    assert np.array_equal(acc2, a + b)
+    # reproducible: the result does not depend on scheduling
+    again, st2 = sc.render(cam, 16, seed=5)
+    assert np.array_equal(again, whole) and st2.rays == st.rays
+    # a different seed gives a different image with the same mean
+    other, _ = sc.render(cam, 16, seed=6)
+    assert not np.array_equal(other, whole)
+    assert abs(other.mean() - whole.mean()) < 0.02 * whole.mean()
+    sc.close()
+
+
+def test_staging_chunks_do_not_change_the_image(monkeypatch):
+    """A tiny staging budget forces several launches per call; the sums must not change."""
+    B = _binding()
+    arrays, cam, _ = load_scene("quads")
+    cam.image_width = 128
+    sc = B.Scene(arrays)
+    whole, st = sc.render(cam, 12, seed=2)
+    monkeypatch.setenv("RT_AMD_STAGE_MB", "1")  # 128*128*16 B = 256 KB per sample -> 4 samples per launch
+    sc2 = B.Scene(arrays)
+    chunked, st2 = sc2.render(cam, 12, seed=2)
+    assert st2.rays == st.rays
+    assert np.allclose(chunked, whole, rtol=1e-6, atol=1e-7)
+    sc.close()
+    sc2.close()
+
+
+def test_counters_and_depth_limit():
+    B = _binding()
+    arrays, cam, _ = load_scene("bouncing_spheres")
+    cam.image_width = 128
+    sc = B.Scene(arrays)
+    acc, st = sc.render(cam, 4, seed=1, counters=True)
+    plain, st0 = sc.render(cam, 4, seed=1)
+    assert np.array_equal(acc, plain) and st.rays == st0.rays
+    assert st.box_tests > st.rays and st.sphere_tests > 0 and st.quad_tests == 0
+    assert sum(st.shades) <= st.rays
+    # max_depth = 1: exactly one ray per path, image = emission + background only
+    cam1 = cam.copy()
+    cam1.max_depth = 1
+    _, st1 = sc.render(cam1, 2, seed=1)
+    assert st1.rays == st1.paths
+    cam0 = cam.copy()
+    cam0.max_depth = 0
+    z, stz = sc.render(cam0, 2, seed=1)
+    assert stz.rays == 0 and not z.any()
+    sc.close()
