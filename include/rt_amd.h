@@ -204,6 +204,10 @@ typedef struct rt_render_stats {
     uint64_t quad_tests;
     uint64_t shades[4];    /* per RT_MAT_*                                   */
     uint64_t noise_evals, image_evals, checker_evals;
+    /* wave-level schedule of the render kernel (RT_RENDER_COUNTERS, BVH scenes):
+     * node-step executions and the lanes active in them, leaf-step executions / lanes,
+     * shading phases / lanes */
+    uint64_t sched[6];
     double kernel_ms;      /* HIP-event time of the render kernels of this call */
 } rt_render_stats;
 

@@ -89,7 +89,7 @@ class RenderStats(C.Structure):
                 ("sphere_tests", C.c_uint64), ("sphere_hits", C.c_uint64),
                 ("quad_tests", C.c_uint64), ("shades", C.c_uint64 * 4),
                 ("noise_evals", C.c_uint64), ("image_evals", C.c_uint64),
-                ("checker_evals", C.c_uint64), ("kernel_ms", C.c_double)]
+                ("checker_evals", C.c_uint64), ("sched", C.c_uint64 * 6), ("kernel_ms", C.c_double)]
 
 
 class SceneInfo(C.Structure):

@@ -68,36 +68,65 @@ struct Ray {
 };
 
 // ------------------------------------------------------------------------------------------
-// Scene as the kernels see it.  All pointers are device pointers.
+// Scene as the kernels see it.  All pointers are device pointers (the kernels
+// may substitute LDS copies of the first five through a SceneView).
 //
 // slots: one per primitive, slot_f4 x 16 bytes each.
 //   sphere: {c1.x c1.y c1.z radius} {cv.x cv.y cv.z 0}
 //   quad  : {n.x n.y n.z D} {Q.x Q.y Q.z w.x} {w.y w.z u.x u.y} {u.z v.x v.y v.z}
-// meta : per slot {type, material, chain (-1 none), prim id}
+// rec_i: per slot {kind, texture, chain (-1 none), prim id}
+//   kind = prim type | material type << 2 | texture type << 4 (texture type of the
+//   material's texture; a solid colour is inlined into rec_f and texture = -1)
+// rec_f: per slot {r g b param}: lambertian / light with a solid texture: the colour;
+//   metal: albedo + fuzz; dielectric: (1,1,1) + refraction index
 // nodes: BVH2 with the two child boxes stored in the parent, 64 bytes:
 //   {lo0.x lo0.y lo0.z hi0.x} {hi0.y hi0.z lo1.x lo1.y} {lo1.z hi1.x hi1.y hi1.z} {ref0 ref1 - -}
 //   ref >= 0: inner node index; ref < 0: leaf, ~ref = slot*2 + type
+// textures: only the textures reachable from a non-solid material texture (re-indexed)
 // xf   : 3 x 16 bytes per wrapper op {type p0 p1 p2} {sa ca sb cb} {sg cg - -}
 enum { TRAV_LINEAR = 0, TRAV_BVH = 1 };
 
+#define RT_KIND_PRIM(k) ((k)&1)
+#define RT_KIND_MAT(k) (((k) >> 2) & 3)
+#define RT_KIND_TEX(k) (((k) >> 4) & 3)
+
 struct DevScene {
     const f4 *slots;
-    const i4 *meta;
     const f4 *nodes;
+    const i4 *rec_i;
+    const f4 *rec_f;
+    const rt_texture *textures;
     const f4 *xf;
     const int *chain_first; // chain c covers ops [chain_first[c], chain_first[c+1])
-    const rt_material *materials;
-    const rt_texture *textures;
     const rt_perlin *perlins;
     const rt_image *images;
     const uint8_t *texels;
     int n_slots;
     int n_nodes;
+    int n_textures;
     int slot_f4;   // 2 (spheres only) or 4
     int traversal; // TRAV_*
     int n_chains;
     int n_xf_ops;
 };
+
+// The five hot arrays, wherever they currently live (HBM or this workgroup's LDS).
+struct SceneView {
+    const f4 *slots;
+    const f4 *nodes;
+    const i4 *rec_i;
+    const f4 *rec_f;
+    const rt_texture *textures;
+};
+RT_HD SceneView global_view(const DevScene &sc) {
+    SceneView v;
+    v.slots = sc.slots;
+    v.nodes = sc.nodes;
+    v.rec_i = sc.rec_i;
+    v.rec_f = sc.rec_f;
+    v.textures = sc.textures;
+    return v;
+}
 
 struct DevCamera {
     rt_camera_frame f;
@@ -110,6 +139,9 @@ struct Counters {
     unsigned long long box_tests, sphere_tests, sphere_hits, quad_tests;
     unsigned long long shades[4];
     unsigned long long noise_evals, image_evals, checker_evals;
+    // wave-level schedule of the decoupled kernel: inner-block executions and the lanes
+    // active in them, leaf-block executions / lanes, shading phases / lanes
+    unsigned long long sched[6];
 };
 
 template <bool COUNT> struct Cnt {
@@ -148,9 +180,13 @@ RT_HD float rng_next(Rng &r) { // uniform in [0,1), 24 bits (rt_constants.h:28-3
     return float(w >> 8) * (1.0f / 16777216.0f);
 }
 
+// sin and cos of 2*pi*u, u in [0,1).  On the device these are the hardware's
+// v_sin_f32 / v_cos_f32, which take their argument in revolutions (absolute error
+// about 1e-6: it only perturbs a random direction).
 RT_HD void sincos_2pi(float u, float &s, float &c) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    sincospif(2.0f * u, &s, &c);
+    s = __builtin_amdgcn_sinf(u);
+    c = __builtin_amdgcn_cosf(u);
 #else
     s = sinf(2.0f * RT_PI * u);
     c = cosf(2.0f * RT_PI * u);
@@ -199,8 +235,7 @@ RT_HD bool sphere_test(f4 g0, f4 g1, f3 o, f3 d, float tm, float tmin, float tma
 }
 
 // quad::hit + is_interior (quad.h:38-69, 80-91).  The interval is closed.
-RT_HD bool quad_test(f4 g0, f4 g1, f4 g2, f4 g3, f3 o, f3 d, float tmin, float tmax, float &t_out,
-                     float &alpha_out, float &beta_out) {
+RT_HD bool quad_test(f4 g0, f4 g1, f4 g2, f4 g3, f3 o, f3 d, float tmin, float tmax, float &t_out) {
     f3 n = xyz(g0);
     float denominator = dot(n, d);
     if (fabsf(denominator) < 1e-8f) return false;
@@ -215,8 +250,6 @@ RT_HD bool quad_test(f4 g0, f4 g1, f4 g2, f4 g3, f3 o, f3 d, float tmin, float t
     float beta = dot(w, cross(u, planar));
     if (!(0.0f <= alpha && alpha <= 1.0f) || !(0.0f <= beta && beta <= 1.0f)) return false;
     t_out = t;
-    alpha_out = alpha;
-    beta_out = beta;
     return true;
 }
 
@@ -300,10 +333,10 @@ struct TraceHit {
 };
 
 // hittable_list::hit (hittable_list.h:29-43): scan in test order with a shrinking
-// interval.  `slots` may point to LDS or HBM.
+// interval.
 template <bool COUNT>
-RT_HD TraceHit trace_linear(const DevScene &sc, const f4 *slots, const i4 *meta, const Ray &r, float tmin,
-                            float tmax, Cnt<COUNT> &cn) {
+RT_HD TraceHit trace_linear(const DevScene &sc, const SceneView &v, const Ray &r, float tmin, float tmax,
+                            Cnt<COUNT> &cn) {
     TraceHit best;
     best.t = tmax;
     best.slot = -1;
@@ -311,23 +344,23 @@ RT_HD TraceHit trace_linear(const DevScene &sc, const f4 *slots, const i4 *meta,
     f3 o = r.o, d = r.d;
     const int stride = sc.slot_f4;
     for (int s = 0; s < sc.n_slots; s++) {
-        i4 m = meta[s];
+        i4 m = v.rec_i[s];
         if (m.z != cur_chain) {
             cur_chain = m.z;
             o = r.o;
             d = r.d;
             if (cur_chain >= 0) chain_ray_to_object(sc, cur_chain, o, d);
         }
-        const f4 *g = slots + (size_t)s * stride;
-        float t, al, be;
+        const f4 *g = v.slots + (size_t)s * stride;
+        float t;
         bool h;
-        if (m.x == RT_PRIM_SPHERE) {
+        if (RT_KIND_PRIM(m.x) == RT_PRIM_SPHERE) {
             RT_COUNT(sph);
             h = sphere_test(g[0], g[1], o, d, r.tm, tmin, best.t, t);
             if constexpr (COUNT) cn.sphh += h ? 1 : 0;
         } else {
             RT_COUNT(quad);
-            h = quad_test(g[0], g[1], g[2], g[3], o, d, tmin, best.t, t, al, be);
+            h = quad_test(g[0], g[1], g[2], g[3], o, d, tmin, best.t, t);
         }
         if (h) {
             best.t = t;
@@ -348,42 +381,47 @@ RT_HD bool tie_prefers_candidate(int cand_id, bool cand_is_quad, int best_id, bo
 }
 
 struct BoxRay { // per-ray constants of the slab test
-    f3 inv;     // 1/d (a zero component is replaced by a huge finite reciprocal)
-    f3 onear;   // -(o*inv) - E : added when computing entry parameters
-    f3 ofar;    // -(o*inv) + E : added when computing exit parameters
+    f3 inv;  // ~1/d (a zero component is replaced by a huge finite reciprocal)
+    f3 oi;   // -(o * inv)
+    float e; // absolute slack: covers the rounding of o*inv inside fma(plane, inv, -o*inv)
 };
 RT_HD float safe_rcp(float d) {
     // |d| below 1e-30 would overflow; a slab that the ray runs (almost) parallel to
     // then yields +-huge parameters of the right sign, which is what the test needs.
+    // The reciprocal only feeds the conservative box test: 1 ulp accuracy is plenty.
     float ad = fabsf(d);
     float m = ad < 1e-30f ? 1e-30f : ad;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return copysignf(__builtin_amdgcn_rcpf(m), d);
+#else
     return copysignf(1.0f / m, d);
+#endif
 }
 RT_HD BoxRay make_box_ray(const Ray &r) {
     BoxRay b;
     b.inv = mk(safe_rcp(r.d.x), safe_rcp(r.d.y), safe_rcp(r.d.z));
     f3 oi = r.o * b.inv;
-    // fma(plane, inv, -o*inv) carries an absolute error of about 2^-24 |o*inv| from
-    // the rounded product; E widens the interval by 2^-21 of that magnitude.
-    const float k = 4.76837158e-7f;
-    f3 e = mk(fabsf(oi.x) * k, fabsf(oi.y) * k, fabsf(oi.z) * k);
-    b.onear = mk(-oi.x - e.x, -oi.y - e.y, -oi.z - e.z);
-    b.ofar = mk(-oi.x + e.x, -oi.y + e.y, -oi.z + e.z);
+    b.oi = -oi;
+    // fma(plane, inv, -o*inv) carries an absolute error of about 2^-24 |o*inv| from the
+    // rounded product; widen the interval by 2^-21 of the largest such magnitude.  A ray
+    // that runs parallel to an axis (huge reciprocal) is excluded: its slab parameters are
+    // +-huge and decide by sign alone.
+    float mx = fabsf(r.d.x) < 1e-30f ? 0.0f : fabsf(oi.x);
+    float my = fabsf(r.d.y) < 1e-30f ? 0.0f : fabsf(oi.y);
+    float mz = fabsf(r.d.z) < 1e-30f ? 0.0f : fabsf(oi.z);
+    b.e = 4.76837158e-7f * fmaxf(mx, fmaxf(my, mz));
     return b;
 }
 // Conservative ray/box overlap on [tmin, tmax]: returns the (slightly early) entry
 // parameter, or +inf when the box is missed.  Boxes are padded at build time.
 RT_HD float box_entry(f3 lo, f3 hi, const BoxRay &b, float tmin, float tmax) {
-    float ax = __builtin_fmaf(lo.x, b.inv.x, b.onear.x), bx = __builtin_fmaf(hi.x, b.inv.x, b.onear.x);
-    float ay = __builtin_fmaf(lo.y, b.inv.y, b.onear.y), by = __builtin_fmaf(hi.y, b.inv.y, b.onear.y);
-    float az = __builtin_fmaf(lo.z, b.inv.z, b.onear.z), bz = __builtin_fmaf(hi.z, b.inv.z, b.onear.z);
-    float cx = __builtin_fmaf(lo.x, b.inv.x, b.ofar.x), dx = __builtin_fmaf(hi.x, b.inv.x, b.ofar.x);
-    float cy = __builtin_fmaf(lo.y, b.inv.y, b.ofar.y), dy = __builtin_fmaf(hi.y, b.inv.y, b.ofar.y);
-    float cz = __builtin_fmaf(lo.z, b.inv.z, b.ofar.z), dz = __builtin_fmaf(hi.z, b.inv.z, b.ofar.z);
+    float ax = __builtin_fmaf(lo.x, b.inv.x, b.oi.x), bx = __builtin_fmaf(hi.x, b.inv.x, b.oi.x);
+    float ay = __builtin_fmaf(lo.y, b.inv.y, b.oi.y), by = __builtin_fmaf(hi.y, b.inv.y, b.oi.y);
+    float az = __builtin_fmaf(lo.z, b.inv.z, b.oi.z), bz = __builtin_fmaf(hi.z, b.inv.z, b.oi.z);
     float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
-    float tf = fminf(fminf(fmaxf(cx, dx), fmaxf(cy, dy)), fminf(fmaxf(cz, dz), tmax));
-    // relative slack for the rounding of the fma results themselves
-    float slack = 9.5367431640625e-7f * fmaxf(fabsf(tn), fabsf(tf));
+    float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
+    // absolute slack e plus a relative one for the rounding of the fma results themselves
+    float slack = __builtin_fmaf(9.5367431640625e-7f, fmaxf(fabsf(tn), fabsf(tf)), b.e + b.e);
     return (tn <= tf + slack) ? tn : RT_INF;
 }
 
@@ -391,74 +429,109 @@ RT_HD float box_entry(f3 lo, f3 hi, const BoxRay &b, float tmin, float tmax) {
 #define RT_STACK_DEPTH 32
 #endif
 
-// BVH traversal, near child first.  StackT is the element type of the per-lane
-// stack, STACK_STRIDE the distance (in elements) between two levels of one lane.
-template <bool COUNT, typename StackT>
-RT_HD TraceHit trace_bvh(const DevScene &sc, const f4 *slots, const f4 *nodes, const i4 *meta, const Ray &r,
-                         float tmin, float tmax, StackT *stack, int stack_stride, Cnt<COUNT> &cn) {
-    TraceHit best;
-    best.t = tmax;
-    best.slot = -1;
-    bool best_is_quad = false;
-    const BoxRay br = make_box_ray(r);
-    const int stride = sc.slot_f4;
-    int sp = 0;
-    int ref = 0; // root
-    for (;;) {
-        if (ref >= 0) {
-            const f4 *n = nodes + (size_t)ref * 4;
-            f4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
-            if constexpr (COUNT) cn.box += 2;
-            float e0 = box_entry(mk(n0.x, n0.y, n0.z), mk(n0.w, n1.x, n1.y), br, tmin, best.t);
-            float e1 = box_entry(mk(n1.z, n1.w, n2.x), mk(n2.y, n2.z, n2.w), br, tmin, best.t);
-            int r0 = __builtin_bit_cast(int, n3.x), r1 = __builtin_bit_cast(int, n3.y);
-            bool h0 = e0 < RT_INF, h1 = e1 < RT_INF;
-            if (h0 && h1) {
-                bool swap = e1 < e0;
-                int nearr = swap ? r1 : r0, farr = swap ? r0 : r1;
-                stack[sp * stack_stride] = (StackT)farr;
-                sp++;
-                ref = nearr;
-                continue;
-            } else if (h0 || h1) {
-                ref = h0 ? r0 : r1;
-                continue;
-            }
-        } else {
-            int code = ~ref;
-            int s = code >> 1;
-            bool is_quad = (code & 1) != 0;
-            const f4 *g = slots + (size_t)s * stride;
-            float t, al, be;
-            bool h;
-            // test against the closed interval [tmin.., best.t] and sort out equality below
-            if (!is_quad) {
-                RT_COUNT(sph);
-                h = sphere_test(g[0], g[1], r.o, r.d, r.tm, tmin, RT_INF, t);
-                if constexpr (COUNT) cn.sphh += h ? 1 : 0;
-                h = h && t <= best.t;
-            } else {
-                RT_COUNT(quad);
-                h = quad_test(g[0], g[1], g[2], g[3], r.o, r.d, tmin, best.t, t, al, be);
-            }
-            if (h) {
-                bool take = t < best.t;
-                if (!take) { // t == best.t: rare
-                    int cid = meta[s].w;
-                    int bid = best.slot >= 0 ? meta[best.slot].w : -1;
-                    take = tie_prefers_candidate(cid, is_quad, bid, best_is_quad);
-                }
-                if (take) {
-                    best.t = t;
-                    best.slot = s;
-                    best_is_quad = is_quad;
-                }
-            }
-        }
-        if (sp == 0) break;
-        sp--;
-        ref = (int)stack[sp * stack_stride];
+// BVH traversal as a resumable state machine, so that a wave can interleave the
+// traversal steps of its 64 rays with shading (rt_kernels.hip) instead of waiting
+// for its slowest ray.  ref >= 0: inner node; ref < 0: leaf (~ref = slot*2 + type);
+// RT_TRAV_DONE: finished.
+#define RT_TRAV_DONE ((int)0x80000000)
+struct Trav {
+    BoxRay br;
+    float best_t;
+    int best_slot;
+    int ref;
+    int sp; // stack offset in elements (already multiplied by the stride)
+    bool best_is_quad;
+};
+RT_HD void trav_begin(Trav &tv, const Ray &r, float tmax) {
+    tv.br = make_box_ray(r);
+    tv.best_t = tmax;
+    tv.best_slot = -1;
+    tv.best_is_quad = false;
+    tv.ref = 0; // root
+    tv.sp = 0;
+}
+template <typename StackT> RT_HD void trav_pop(Trav &tv, const StackT *stack, int stack_stride) {
+    if (tv.sp == 0) {
+        tv.ref = RT_TRAV_DONE;
+    } else {
+        tv.sp -= stack_stride;
+        tv.ref = (int)stack[tv.sp];
     }
+}
+// One inner node (requires tv.ref >= 0): tests both children, descends into the
+// nearer one that is hit and pushes the other.
+template <bool COUNT, typename StackT>
+RT_HD void trav_inner(Trav &tv, const f4 *nodes, float tmin, StackT *stack, int stack_stride, Cnt<COUNT> &cn) {
+    const f4 *n = nodes + (size_t)tv.ref * 4;
+    f4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+    if constexpr (COUNT) cn.box += 2;
+    float e0 = box_entry(mk(n0.x, n0.y, n0.z), mk(n0.w, n1.x, n1.y), tv.br, tmin, tv.best_t);
+    float e1 = box_entry(mk(n1.z, n1.w, n2.x), mk(n2.y, n2.z, n2.w), tv.br, tmin, tv.best_t);
+    int r0 = __builtin_bit_cast(int, n3.x), r1 = __builtin_bit_cast(int, n3.y);
+    bool h0 = e0 < RT_INF, h1 = e1 < RT_INF;
+    if (h0 && h1) {
+        bool swap = e1 < e0;
+        stack[tv.sp] = (StackT)(swap ? r0 : r1);
+        tv.sp += stack_stride;
+        tv.ref = swap ? r1 : r0;
+    } else if (h0 || h1) {
+        tv.ref = h0 ? r0 : r1;
+    } else {
+        trav_pop(tv, stack, stack_stride);
+    }
+}
+// Exact test of one leaf against the current best (ties included).
+template <bool COUNT>
+RT_HD void trav_test_leaf(Trav &tv, int leaf_ref, const DevScene &sc, const SceneView &v, const Ray &r,
+                          float tmin, Cnt<COUNT> &cn) {
+    int code = ~leaf_ref;
+    int s = code >> 1;
+    bool is_quad = (code & 1) != 0;
+    const f4 *g = v.slots + (size_t)s * sc.slot_f4;
+    float t;
+    bool h;
+    // candidates at t == best_t are admitted here and sorted out by the tie rule
+    if (!is_quad) {
+        RT_COUNT(sph);
+        h = sphere_test(g[0], g[1], r.o, r.d, r.tm, tmin, RT_INF, t);
+        if constexpr (COUNT) cn.sphh += h ? 1 : 0;
+        h = h && t <= tv.best_t;
+    } else {
+        RT_COUNT(quad);
+        h = quad_test(g[0], g[1], g[2], g[3], r.o, r.d, tmin, tv.best_t, t);
+    }
+    if (h) {
+        bool take = t < tv.best_t;
+        if (!take) { // t == best_t: rare
+            int cid = v.rec_i[s].w;
+            int bid = tv.best_slot >= 0 ? v.rec_i[tv.best_slot].w : -1;
+            take = tie_prefers_candidate(cid, is_quad, bid, tv.best_is_quad);
+        }
+        if (take) {
+            tv.best_t = t;
+            tv.best_slot = s;
+            tv.best_is_quad = is_quad;
+        }
+    }
+}
+
+// Whole traversal of one ray (parity entry point, host logic check).
+template <bool COUNT, typename StackT>
+RT_HD TraceHit trace_bvh(const DevScene &sc, const SceneView &v, const Ray &r, float tmin, float tmax,
+                         StackT *stack, int stack_stride, Cnt<COUNT> &cn) {
+    Trav tv;
+    trav_begin(tv, r, tmax);
+    while (tv.ref != RT_TRAV_DONE) {
+        if (tv.ref >= 0) {
+            trav_inner<COUNT, StackT>(tv, v.nodes, tmin, stack, stack_stride, cn);
+        } else {
+            trav_test_leaf<COUNT>(tv, tv.ref, sc, v, r, tmin, cn);
+            trav_pop(tv, stack, stack_stride);
+        }
+    }
+    TraceHit best;
+    best.t = tv.best_t;
+    best.slot = tv.best_slot;
     return best;
 }
 
@@ -469,7 +542,7 @@ struct Surf {
     f3 p, n;       // world-space hit point and shading normal (against the ray)
     f3 outward;    // spheres: object-space outward unit normal (for get_sphere_uv)
     float u, v;    // quads: alpha, beta
-    int material, prim, type;
+    i4 rec;        // the slot's {kind, texture, chain, prim id}
     bool front;
 };
 
@@ -480,28 +553,24 @@ RT_HD void sphere_uv(f3 p, float &u, float &v) { // sphere.h:96-113
     v = theta / RT_PI;
 }
 
-RT_HD Surf surface_at(const DevScene &sc, const f4 *slots, const i4 *meta, const Ray &r, TraceHit h) {
+RT_HD Surf surface_at(const DevScene &sc, const SceneView &vw, const Ray &r, TraceHit h) {
     Surf s;
-    i4 m = meta[h.slot];
-    s.type = m.x;
-    s.material = m.y;
-    s.prim = m.w;
+    i4 m = vw.rec_i[h.slot];
+    s.rec = m;
     f3 o = r.o, d = r.d;
     if (m.z >= 0) chain_ray_to_object(sc, m.z, o, d);
-    const f4 *g = slots + (size_t)h.slot * sc.slot_f4;
+    const f4 *g = vw.slots + (size_t)h.slot * sc.slot_f4;
     f3 p = o + h.t * d; // ray.h:20
     f3 outward;
     s.u = 0.0f;
     s.v = 0.0f;
-    if (m.x == RT_PRIM_SPHERE) {
+    if (RT_KIND_PRIM(m.x) == RT_PRIM_SPHERE) {
         f4 g0 = g[0], g1 = g[1];
         f3 center = xyz(g0) + r.tm * xyz(g1);
         outward = (p - center) / g0.w; // sphere.h:68
-        s.outward = outward;
     } else {
         f4 g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
         outward = xyz(g0);
-        s.outward = outward;
         f3 planar = p - xyz(g1);
         f3 w = mk(g1.w, g2.x, g2.y);
         f3 u = mk(g2.z, g2.w, g3.x);
@@ -509,6 +578,7 @@ RT_HD Surf surface_at(const DevScene &sc, const f4 *slots, const i4 *meta, const
         s.u = dot(w, cross(planar, v));
         s.v = dot(w, cross(u, planar));
     }
+    s.outward = outward;
     s.front = dot(d, outward) < 0; // hittable.h:20-25
     f3 n = s.front ? outward : -outward;
     if (m.z >= 0) chain_hit_to_world(sc, m.z, p, n);
@@ -556,28 +626,31 @@ RT_HD float perlin_turb(const rt_perlin &pn, f3 p, int depth) {
     return fabsf(accum);
 }
 
-template <bool COUNT> RT_HD f3 texture_value(const DevScene &sc, int tex, const Surf &s, Cnt<COUNT> &cn) {
-    const rt_texture *t = &sc.textures[tex];
-    for (int guard = 0; guard < 16 && t->type == RT_TEX_CHECKER; guard++) { // texture.h:40-47
+// Value of a non-solid texture (solid colours never get here: they are inlined
+// into the slot record).
+template <bool COUNT>
+RT_HD f3 texture_value(const DevScene &sc, const SceneView &vw, int tex, const Surf &s, Cnt<COUNT> &cn) {
+    rt_texture t = vw.textures[tex];
+    for (int guard = 0; guard < 16 && t.type == RT_TEX_CHECKER; guard++) { // texture.h:40-47
         RT_COUNT(chk);
-        int xi = int(floorf(t->scale * s.p.x));
-        int yi = int(floorf(t->scale * s.p.y));
-        int zi = int(floorf(t->scale * s.p.z));
+        int xi = int(floorf(t.scale * s.p.x));
+        int yi = int(floorf(t.scale * s.p.y));
+        int zi = int(floorf(t.scale * s.p.z));
         bool is_even = (xi + yi + zi) % 2 == 0;
-        t = &sc.textures[is_even ? t->even : t->odd];
+        t = vw.textures[is_even ? t.even : t.odd];
     }
-    if (t->type == RT_TEX_SOLID) return mk(t->color[0], t->color[1], t->color[2]);
-    if (t->type == RT_TEX_NOISE) { // texture.h:85-90
+    if (t.type == RT_TEX_SOLID) return mk(t.color[0], t.color[1], t.color[2]);
+    if (t.type == RT_TEX_NOISE) { // texture.h:85-90
         RT_COUNT(noise);
-        float ph = t->scale * s.p.z + 10.0f * perlin_turb(sc.perlins[t->perlin], s.p, 7);
+        float ph = t.scale * s.p.z + 10.0f * perlin_turb(sc.perlins[t.perlin], s.p, 7);
         return mk(0.5f, 0.5f, 0.5f) * (1.0f + sinf(ph));
     }
-    if (t->type == RT_TEX_IMAGE) { // texture.h:60-74, rtw_stb_image.h:69-94
+    if (t.type == RT_TEX_IMAGE) { // texture.h:60-74, rtw_stb_image.h:69-94
         RT_COUNT(img);
-        if (t->image < 0) return mk(0.0f, 0.0f, 1.0f);
+        if (t.image < 0) return mk(0.0f, 0.0f, 1.0f);
         float u = s.u, v = s.v;
-        if (s.type == RT_PRIM_SPHERE) sphere_uv(s.outward, u, v);
-        rt_image im = sc.images[t->image];
+        if (RT_KIND_PRIM(s.rec.x) == RT_PRIM_SPHERE) sphere_uv(s.outward, u, v);
+        rt_image im = sc.images[t.image];
         u = u < 0.0f ? 0.0f : (u > 1.0f ? 1.0f : u);
         float vc = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
         v = 1.0f - vc;
@@ -646,29 +719,24 @@ RT_HD float schlick(float cosine, float ri) { // material.h:97-103
 
 // Returns true while the path continues.
 template <bool COUNT>
-RT_HD bool shade_hit(const DevScene &sc, const DevCamera &cam, PathState &ps, const Surf &s, Cnt<COUNT> &cn) {
-    const rt_material m = sc.materials[s.material];
-    if (m.type == RT_MAT_DIFFUSE_LIGHT) { // material.h:113-115: emits on both faces, never scatters
+RT_HD bool shade_hit(const DevScene &sc, const SceneView &vw, int slot, PathState &ps, const Surf &s,
+                     Cnt<COUNT> &cn) {
+    const int kind = s.rec.x;
+    const int mat = RT_KIND_MAT(kind);
+    const f4 rf = vw.rec_f[slot];
+    // colour of the material's texture: inlined when solid
+    f3 col = mk(rf.x, rf.y, rf.z);
+    if ((mat == RT_MAT_LAMBERTIAN || mat == RT_MAT_DIFFUSE_LIGHT) && RT_KIND_TEX(kind) != RT_TEX_SOLID)
+        col = texture_value<COUNT>(sc, vw, s.rec.y, s, cn);
+    if (mat == RT_MAT_DIFFUSE_LIGHT) { // material.h:113-115: emits on both faces, never scatters
         RT_COUNT(sh3);
-        ps.L = ps.L + ps.beta * texture_value<COUNT>(sc, m.texture, s, cn);
+        ps.L = ps.L + ps.beta * col;
         return false;
     }
-    f3 dir, att;
-    if (m.type == RT_MAT_LAMBERTIAN) { // material.h:30-42
-        RT_COUNT(sh0);
-        dir = s.n + sample_unit_vector(ps.rng);
-        if (fabsf(dir.x) < 1e-8f && fabsf(dir.y) < 1e-8f && fabsf(dir.z) < 1e-8f) dir = s.n;
-        att = texture_value<COUNT>(sc, m.texture, s, cn);
-    } else if (m.type == RT_MAT_METAL) { // material.h:53-60
-        RT_COUNT(sh1);
-        f3 reflected = reflect(ps.ray.d, s.n);
-        dir = unit(reflected) + (m.param * sample_unit_vector(ps.rng));
-        att = mk(m.albedo[0], m.albedo[1], m.albedo[2]);
-        if (!(dot(dir, s.n) > 0)) return false; // absorbed: contributes nothing
-    } else { // dielectric, material.h:72-90
+    f3 dir;
+    if (mat == RT_MAT_DIELECTRIC) { // material.h:72-90
         RT_COUNT(sh2);
-        att = mk(1.0f, 1.0f, 1.0f);
-        float ri = s.front ? (1.0f / m.param) : m.param;
+        float ri = s.front ? (1.0f / rf.w) : rf.w;
         f3 unit_direction = unit(ps.ray.d);
         float cos_theta = fminf(dot(-unit_direction, s.n), 1.0f);
         float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
@@ -678,18 +746,30 @@ RT_HD bool shade_hit(const DevScene &sc, const DevCamera &cam, PathState &ps, co
             dir = reflect(unit_direction, s.n);
         else
             dir = refract(unit_direction, s.n, ri);
+    } else {
+        // lambertian (material.h:30-42) and metal (material.h:53-60) both draw one
+        // random unit vector
+        f3 rv = sample_unit_vector(ps.rng);
+        if (mat == RT_MAT_LAMBERTIAN) {
+            RT_COUNT(sh0);
+            dir = s.n + rv;
+            if (fabsf(dir.x) < 1e-8f && fabsf(dir.y) < 1e-8f && fabsf(dir.z) < 1e-8f) dir = s.n;
+        } else {
+            RT_COUNT(sh1);
+            f3 reflected = reflect(ps.ray.d, s.n);
+            dir = unit(reflected) + (rf.w * rv);
+            if (!(dot(dir, s.n) > 0)) return false; // absorbed: contributes nothing
+        }
     }
-    ps.beta = ps.beta * att;
+    ps.beta = ps.beta * col;
     ps.ray.o = s.p;
     ps.ray.d = dir;
     return true;
 }
 
 // Starts the path of (pixel, global sample index): camera.h:44-46.
-RT_HD PathState path_start(const DevCamera &cam, uint32_t seed, unsigned pixel, unsigned sample) {
+RT_HD PathState path_start(const DevCamera &cam, uint32_t seed, unsigned pixel, int px, int py, unsigned sample) {
     PathState ps;
-    int py = (int)(pixel / (unsigned)cam.f.image_width);
-    int px = (int)(pixel - (unsigned)py * (unsigned)cam.f.image_width);
     ps.rng = rng_seed(seed, pixel, sample);
     ps.ray = camera_ray(cam, px, py, ps.rng);
     ps.beta = mk(1.0f, 1.0f, 1.0f);
@@ -698,25 +778,34 @@ RT_HD PathState path_start(const DevCamera &cam, uint32_t seed, unsigned pixel, 
     return ps;
 }
 
-// One segment of ray_color: trace, then miss / emit / scatter.  Returns true while
-// the path continues; when it returns false ps.L holds the path's radiance.
+// The part of a ray_color segment that follows the closest-hit query: miss ->
+// background (camera.h:148-161), otherwise emission / scatter (camera.h:164-173).
+// Returns true while the path continues (ps.ray then holds the scattered ray).
+template <bool COUNT>
+RT_HD bool path_after_trace(const DevScene &sc, const SceneView &vw, const DevCamera &cam, PathState &ps,
+                            TraceHit h, Cnt<COUNT> &cn) {
+    if (h.slot < 0) {
+        ps.L = ps.L + ps.beta * mk(cam.background[0], cam.background[1], cam.background[2]);
+        return false;
+    }
+    Surf s = surface_at(sc, vw, ps.ray, h);
+    ps.depth--;
+    return shade_hit<COUNT>(sc, vw, h.slot, ps, s, cn) && ps.depth > 0; // depth 0: camera.h:141 returns black
+}
+
+// One whole segment of ray_color: trace, then miss / emit / scatter.  Returns true
+// while the path continues; when it returns false ps.L holds the path's radiance.
 template <int TRAV, bool COUNT, typename StackT>
-RT_HD bool path_step(const DevScene &sc, const f4 *slots, const f4 *nodes, const DevCamera &cam, PathState &ps,
-                     StackT *stack, int stack_stride, unsigned &n_rays, Cnt<COUNT> &cn) {
+RT_HD bool path_step(const DevScene &sc, const SceneView &vw, const DevCamera &cam, PathState &ps, StackT *stack,
+                     int stack_stride, unsigned &n_rays, Cnt<COUNT> &cn) {
     if (ps.depth <= 0) return false; // camera.h:141
     n_rays++;
     TraceHit h;
     if constexpr (TRAV == TRAV_LINEAR)
-        h = trace_linear<COUNT>(sc, slots, sc.meta, ps.ray, 0.001f, RT_INF, cn);
+        h = trace_linear<COUNT>(sc, vw, ps.ray, 0.001f, RT_INF, cn);
     else
-        h = trace_bvh<COUNT, StackT>(sc, slots, nodes, sc.meta, ps.ray, 0.001f, RT_INF, stack, stack_stride, cn);
-    if (h.slot < 0) { // camera.h:148-161
-        ps.L = ps.L + ps.beta * mk(cam.background[0], cam.background[1], cam.background[2]);
-        return false;
-    }
-    Surf s = surface_at(sc, slots, sc.meta, ps.ray, h);
-    ps.depth--;
-    return shade_hit<COUNT>(sc, cam, ps, s, cn);
+        h = trace_bvh<COUNT, StackT>(sc, vw, ps.ray, 0.001f, RT_INF, stack, stack_stride, cn);
+    return path_after_trace<COUNT>(sc, vw, cam, ps, h, cn);
 }
 
 } // namespace rtc

@@ -280,7 +280,9 @@ class BvhBuilder {
 // Flat scene on the host.
 struct HostScene {
     std::vector<f4> slots;       // n_prims * slot_f4
-    std::vector<i4> meta;        // per slot {type, material, chain, prim id}
+    std::vector<i4> rec_i;       // per slot {kind, texture, chain, prim id}   (rt_core.h)
+    std::vector<f4> rec_f;       // per slot {r g b param}
+    std::vector<rt_texture> textures; // textures reachable from non-solid material textures
     std::vector<f4> nodes;       // 4 per BVH node (empty: linear scan)
     std::vector<f4> xf;          // 3 per wrapper op, packed chain by chain
     std::vector<int> chain_first; // n_chains + 1
@@ -381,7 +383,7 @@ inline int flatten_scene(const rt_scene_desc *d, uint32_t flags, HostScene &out,
     for (int i = 0; i < n; i++) (types[i] == RT_PRIM_SPHERE ? out.n_spheres : out.n_quads)++;
 
     std::vector<f4> &slots = out.slots;
-    std::vector<i4> &meta = out.meta;
+    std::vector<i4> meta;
     std::vector<f4> &nodes = out.nodes;
     meta.resize(n);
     if (linear) {
@@ -399,6 +401,54 @@ inline int flatten_scene(const rt_scene_desc *d, uint32_t flags, HostScene &out,
         }
         out.n_nodes = (int)(nodes.size() / 4);
         out.bvh_depth = bo.max_inner_depth + 1;
+    }
+
+    // per-slot shading records: the material (and a solid colour) inlined, so that the
+    // common case costs one 32-byte read instead of a chain of dependent table lookups
+    {
+        std::vector<int> tex_map(d->n_textures, -1);
+        std::vector<rt_texture> &tex_out = out.textures;
+        // depth-first copy of a texture and what it refers to; returns its new index
+        struct Copier {
+            const rt_scene_desc *d;
+            std::vector<int> &map;
+            std::vector<rt_texture> &outv;
+            int visit(int t) {
+                if (map[t] >= 0) return map[t];
+                int id = (int)outv.size();
+                map[t] = id;
+                outv.push_back(d->textures[t]);
+                if (d->textures[t].type == RT_TEX_CHECKER) {
+                    int e = visit(d->textures[t].even), o = visit(d->textures[t].odd);
+                    outv[id].even = e;
+                    outv[id].odd = o;
+                }
+                return id;
+            }
+        } copier{d, tex_map, tex_out};
+        out.rec_i.resize(n);
+        out.rec_f.resize(n);
+        for (int sl = 0; sl < n; sl++) {
+            const i4 m = meta[sl]; // {type, material, chain, prim id}
+            const rt_material &mat = d->materials[m.y];
+            int tex_type = RT_TEX_SOLID, tex_id = -1;
+            f4 rf{0.0f, 0.0f, 0.0f, 0.0f};
+            if (mat.type == RT_MAT_LAMBERTIAN || mat.type == RT_MAT_DIFFUSE_LIGHT) {
+                const rt_texture &t = d->textures[mat.texture];
+                if (t.type == RT_TEX_SOLID) {
+                    rf = f4{t.color[0], t.color[1], t.color[2], 0.0f};
+                } else {
+                    tex_type = t.type;
+                    tex_id = copier.visit(mat.texture);
+                }
+            } else if (mat.type == RT_MAT_METAL) {
+                rf = f4{mat.albedo[0], mat.albedo[1], mat.albedo[2], mat.param};
+            } else { // dielectric: attenuation (1,1,1), material.h:74
+                rf = f4{1.0f, 1.0f, 1.0f, mat.param};
+            }
+            out.rec_i[sl] = i4{m.x | (mat.type << 2) | (tex_type << 4), tex_id, m.z, m.w};
+            out.rec_f[sl] = rf;
+        }
     }
 
     // wrapper ops / chains (only the linear scan applies them at run time)

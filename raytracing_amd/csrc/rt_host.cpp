@@ -70,7 +70,8 @@ struct rt_scene {
 namespace {
 
 template <class T> int upload(rt_scene *s, const std::vector<T> &v, const T **out) {
-    size_t bytes = std::max<size_t>(v.size() * sizeof(T), 16);
+    // rounded up to whole 16-byte words: the kernels stage tables into LDS 16 bytes at a time
+    size_t bytes = std::max<size_t>((v.size() * sizeof(T) + 15) / 16 * 16, 16);
     void *p = nullptr;
     RT_HIP(hipMalloc(&p, bytes));
     s->allocs.push_back(p);
@@ -126,6 +127,14 @@ int validate(const rt_scene_desc *d) {
             return fail(RT_ERR_ARG, "chain %d: ops out of range", i);
     }
     return RT_OK;
+}
+
+// Bytes of LDS the staged arrays take: slots, nodes, both per-slot records, textures
+// (the latter padded to 16 bytes).  Must match the kernels' staging order.
+size_t scene_lds_bytes(const rtc::DevScene &dv) {
+    size_t words = (size_t)dv.n_slots * dv.slot_f4 + (size_t)dv.n_nodes * 4 + (size_t)dv.n_slots * 2;
+    size_t tex = ((size_t)dv.n_textures * sizeof(rt_texture) + 15) / 16;
+    return (words + tex) * sizeof(f4);
 }
 
 int set_device(int device) {
@@ -186,7 +195,8 @@ int rt_scene_create(const rt_scene_desc *d, int device, uint32_t flags, rt_scene
     const bool linear = hs.linear;
     const int slot_f4 = hs.slot_f4;
     const std::vector<f4> &slots = hs.slots, &nodes = hs.nodes, &xf_packed = hs.xf;
-    const std::vector<i4> &meta = hs.meta;
+    const std::vector<i4> &rec_i = hs.rec_i;
+    const std::vector<f4> &rec_f = hs.rec_f;
     const std::vector<int> &chain_first = hs.chain_first;
 
     rt_scene *s = new rt_scene();
@@ -199,19 +209,18 @@ int rt_scene_create(const rt_scene_desc *d, int device, uint32_t flags, rt_scene
     s->info.n_nodes = hs.n_nodes;
     s->info.bvh_depth = hs.bvh_depth;
 
-    std::vector<rt_material> mats(d->materials, d->materials + d->n_materials);
-    std::vector<rt_texture> texs(d->textures, d->textures + d->n_textures);
+    const std::vector<rt_texture> &texs = hs.textures;
     std::vector<rt_perlin> perl(d->perlins, d->perlins + d->n_perlins);
     std::vector<rt_image> imgs(d->images, d->images + d->n_images);
     std::vector<uint8_t> texels(d->texels, d->texels + d->n_texel_bytes);
 
     rtc::DevScene &dv = s->dev;
     rc = upload(s, slots, &dv.slots);
-    if (rc == RT_OK) rc = upload(s, meta, &dv.meta);
+    if (rc == RT_OK) rc = upload(s, rec_i, &dv.rec_i);
+    if (rc == RT_OK) rc = upload(s, rec_f, &dv.rec_f);
     if (rc == RT_OK) rc = upload(s, nodes, &dv.nodes);
     if (rc == RT_OK) rc = upload(s, xf_packed, &dv.xf);
     if (rc == RT_OK) rc = upload(s, chain_first, &dv.chain_first);
-    if (rc == RT_OK) rc = upload(s, mats, &dv.materials);
     if (rc == RT_OK) rc = upload(s, texs, &dv.textures);
     if (rc == RT_OK) rc = upload(s, perl, &dv.perlins);
     if (rc == RT_OK) rc = upload(s, imgs, &dv.images);
@@ -233,6 +242,7 @@ int rt_scene_create(const rt_scene_desc *d, int device, uint32_t flags, rt_scene
     s->d_counters = const_cast<rtc::Counters *>(dc);
     dv.n_slots = n;
     dv.n_nodes = (int)(nodes.size() / 4);
+    dv.n_textures = (int)texs.size();
     dv.slot_f4 = slot_f4;
     dv.traversal = linear ? rtc::TRAV_LINEAR : rtc::TRAV_BVH;
     dv.n_chains = d->n_chains;
@@ -248,7 +258,7 @@ int rt_scene_create(const rt_scene_desc *d, int device, uint32_t flags, rt_scene
     }
 
     // Does the geometry fit LDS next to the traversal stacks?
-    size_t scene_bytes = ((size_t)n * slot_f4 + nodes.size()) * sizeof(f4);
+    size_t scene_bytes = scene_lds_bytes(dv);
     bool short_ok = dv.n_nodes < 32768 && n < 16384;
     s->info.lds_resident = 0;
     if (!(flags & RT_SCENE_FORCE_GLOBAL) && short_ok) {
@@ -275,7 +285,7 @@ LaunchGeom choose_geom(const rt_scene *s) {
     const rtc::DevScene &dv = s->dev;
     const bool bvh = dv.traversal == rtc::TRAV_BVH;
     const int levels = s->info.bvh_depth + 1;
-    size_t scene_bytes = ((size_t)dv.n_slots * dv.slot_f4 + (size_t)dv.n_nodes * 4) * sizeof(f4);
+    size_t scene_bytes = scene_lds_bytes(dv);
     lg.lds_scene = s->info.lds_resident != 0;
     int block = 1024;
     const char *env_block = getenv("RT_AMD_BLOCK");
@@ -290,12 +300,17 @@ LaunchGeom choose_geom(const rt_scene *s) {
         }
     }
     int per_cu_lds = kMaxLdsBytes / std::max(lg.lds_bytes, 1);
-    int per_cu_waves = 2048 / lg.block; // 32 waves per CU
+    int per_cu_waves = 1024 / lg.block; // 16 waves per CU: the kernels use up to 128 VGPRs
     int per_cu = std::max(1, std::min(per_cu_lds, per_cu_waves));
     const char *env_mult = getenv("RT_AMD_BLOCKS_PER_CU");
     if (env_mult) per_cu = std::max(1, atoi(env_mult));
     lg.grid = s->n_cu * per_cu;
     return lg;
+}
+
+int env_int(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
 }
 
 size_t stage_budget_bytes() {
@@ -366,10 +381,14 @@ int rt_render_device(rt_scene *s, const rt_camera_desc *cam, const rt_render_opt
         rp.sample_begin = opts->sample_begin + done;
         rp.sample_count = sc_n;
         rp.seed = opts->seed;
-        rp.n_paths = (unsigned long long)((n_pixels + 63) / 64) * 64ull * (unsigned long long)sc_n;
+        rp.n_sample_groups = ((unsigned)sc_n + RT_POOL_SAMPLES - 1) / RT_POOL_SAMPLES;
+        rp.n_chunks = (unsigned)((n_pixels + 63) / 64) * rp.n_sample_groups;
         rp.stage = s->stage;
-        rp.next_path = s->d_words;
+        rp.next_chunk = reinterpret_cast<unsigned *>(s->d_words);
         rp.counters = count ? s->d_counters : nullptr;
+        rp.scheduler = env_int("RT_AMD_SCHEDULER", 0);
+        rp.min_ready = std::max(1, std::min(64, env_int("RT_AMD_MIN_READY", 24)));
+        rp.leaf_min = std::max(1, std::min(64, env_int("RT_AMD_LEAF_MIN", 1)));
         RT_HIP(hipMemsetAsync(s->d_words, 0, sizeof(unsigned long long), stream));
         hipEvent_t p0 = nullptr, p1 = nullptr;
         if (s->profiling) {
@@ -413,6 +432,7 @@ int rt_render_device(rt_scene *s, const rt_camera_desc *cam, const rt_render_opt
             stats->noise_evals = c.noise_evals;
             stats->image_evals = c.image_evals;
             stats->checker_evals = c.checker_evals;
+            for (int k = 0; k < 6; k++) stats->sched[k] = c.sched[k];
         }
     }
     return RT_OK;

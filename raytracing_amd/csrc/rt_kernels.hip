@@ -1,15 +1,21 @@
 // rt_kernels.hip — gfx950 kernels of the path tracer.
 //
-//   render_mega   persistent wave64 megakernel: every lane owns one path at a time and
-//                 pulls the next (pixel, sample) from a per-wave pool refilled from one
-//                 global counter; geometry (primitive slots + BVH nodes) is staged into
-//                 LDS once per workgroup when it fits, traversal stacks live in LDS.
-//   reduce_stage  sums the per-path radiance records of a launch, in sample order, into
-//                 the caller's fp32 accumulation image (camera.h:43-47's pixel_color +=).
-//   trace_batch   closest hit for a batch of rays (the parity entry point).
+//   render_mega_bvh  persistent wave64 megakernel for BVH scenes.  Every lane is a small
+//                    state machine (idle -> traversing -> hit ready); the wave interleaves
+//                    traversal steps of its 64 rays with shading phases, so it never idles
+//                    for its slowest ray.  Geometry, BVH nodes, per-slot shading records
+//                    and the texture table are staged into LDS once per workgroup when they
+//                    fit; traversal stacks live in LDS.
+//   render_mega      the same persistent scheme with one whole ray per lane per iteration:
+//                    used for small scenes that are scanned linearly (uniform control flow).
+//   reduce_stage     sums the per-path radiance records of a launch, in sample order, into
+//                    the caller's fp32 accumulation image (camera.h:43-47's pixel_color +=).
+//   trace_batch      closest hit for a batch of rays (the parity entry point).
 //
 // Replaces camera::render's triple loop (camera.h:40-47) and everything below it.
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 
 #include "rt_core.h"
 #include "rt_launch.h"
@@ -18,11 +24,7 @@ using namespace rtc;
 
 namespace {
 
-__device__ __forceinline__ unsigned long long wave_bcast64(unsigned long long v) {
-    unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(v & 0xffffffffull));
-    unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return ((unsigned long long)hi << 32) | lo;
-}
+__device__ __forceinline__ unsigned wave_bcast32(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
 
 template <bool COUNT> __device__ __forceinline__ void flush_counters(Counters *out, const Cnt<COUNT> &cn) {
     if constexpr (COUNT) {
@@ -45,96 +47,282 @@ __device__ __forceinline__ void stage_to_lds(f4 *dst, const f4 *src, int n) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
 }
 
+// Stages slots, nodes, the per-slot records and the texture table into LDS (the layout
+// matches scene_lds_bytes() in rt_host.cpp); returns the first free 16-byte word.
+__device__ __forceinline__ f4 *stage_scene(const DevScene &sc, f4 *smem, SceneView &v) {
+    int n_slot_words = sc.n_slots * sc.slot_f4;
+    int n_node_words = sc.n_nodes * 4;
+    int n_tex_words = (sc.n_textures * (int)sizeof(rt_texture) + 15) / 16;
+    f4 *p = smem;
+    stage_to_lds(p, sc.slots, n_slot_words);
+    v.slots = p;
+    p += n_slot_words;
+    stage_to_lds(p, sc.nodes, n_node_words);
+    v.nodes = p;
+    p += n_node_words;
+    stage_to_lds(p, reinterpret_cast<const f4 *>(sc.rec_i), sc.n_slots);
+    v.rec_i = reinterpret_cast<const i4 *>(p);
+    p += sc.n_slots;
+    stage_to_lds(p, sc.rec_f, sc.n_slots);
+    v.rec_f = p;
+    p += sc.n_slots;
+    // the device copy of the texture table is padded to whole 16-byte words
+    stage_to_lds(p, reinterpret_cast<const f4 *>(sc.textures), n_tex_words);
+    v.textures = reinterpret_cast<const rt_texture *>(p);
+    p += n_tex_words;
+    __syncthreads();
+    return p;
+}
+
+// Per-wave pool of paths.  The global counter hands out chunks of 64 pixels x
+// RT_POOL_SAMPLES samples; everything per chunk is wave-uniform.
+struct WavePool {
+    unsigned k, k_end;      // next / end path within the current chunk (k_end = 0: no chunk)
+    unsigned strip, s_base; // first pixel = strip * 64, first local sample of the chunk
+    unsigned x0, y0;        // pixel coordinates of the strip's first pixel
+    bool exhausted;
+};
+
+__device__ __forceinline__ void pool_init(WavePool &wp) {
+    wp.k = wp.k_end = 0;
+    wp.strip = wp.s_base = wp.x0 = wp.y0 = 0;
+    wp.exhausted = false;
+}
+
+// Makes sure the wave holds a chunk with paths left, if any remain.  Wave-uniform.
+__device__ __forceinline__ void pool_refill(WavePool &wp, const RenderParams &rp, int lane) {
+    if (wp.k < wp.k_end || wp.exhausted) return;
+    unsigned chunk = 0;
+    if (lane == 0) chunk = atomicAdd(rp.next_chunk, 1u);
+    chunk = wave_bcast32(chunk);
+    if (chunk >= rp.n_chunks) {
+        wp.exhausted = true;
+        return;
+    }
+    unsigned strip = chunk / rp.n_sample_groups;
+    unsigned sg = chunk - strip * rp.n_sample_groups;
+    wp.strip = strip;
+    wp.s_base = sg * RT_POOL_SAMPLES;
+    unsigned left = (unsigned)rp.sample_count - wp.s_base;
+    wp.k = 0;
+    wp.k_end = 64u * (left < RT_POOL_SAMPLES ? left : RT_POOL_SAMPLES);
+    unsigned first = strip * 64u;
+    wp.y0 = first / (unsigned)rp.width;
+    wp.x0 = first - wp.y0 * (unsigned)rp.width;
+}
+
+// Decodes path index `k` of the current chunk; false if it falls outside the image.
+__device__ __forceinline__ bool pool_decode(const WavePool &wp, const RenderParams &rp, unsigned k,
+                                            unsigned &pixel, unsigned &s_local, int &px, int &py) {
+    unsigned j = k & 63u;
+    s_local = wp.s_base + (k >> 6);
+    pixel = wp.strip * 64u + j;
+    unsigned x = wp.x0 + j, y = wp.y0;
+    while (x >= (unsigned)rp.width) {
+        x -= (unsigned)rp.width;
+        y++;
+    }
+    px = (int)x;
+    py = (int)y;
+    return pixel < (unsigned)rp.n_pixels;
+}
+
+__device__ __forceinline__ void write_record(const RenderParams &rp, unsigned s_local, unsigned pixel, f3 L,
+                                             unsigned n_rays) {
+    f4 rec;
+    rec.x = L.x;
+    rec.y = L.y;
+    rec.z = L.z;
+    rec.w = __builtin_bit_cast(float, n_rays);
+    rp.stage[(size_t)s_local * (size_t)rp.n_pixels + pixel] = rec;
+}
+
+// ------------------------------------------------------------------------------------------
+// One whole ray per lane per iteration.  Linear scenes: every lane walks the same
+// primitive list, so the traversal itself is divergence-free.
 template <int TRAV, bool LDS_SCENE, bool COUNT>
 __global__ void __launch_bounds__(RT_MEGA_MAX_THREADS)
 render_mega(DevScene sc, DevCamera cam, RenderParams rp) {
     extern __shared__ f4 smem[];
-    // LDS layout: [slots][nodes][stacks]
-    const f4 *slots = sc.slots;
-    const f4 *nodes = sc.nodes;
-    f4 *stack_base_f4 = smem;
-    if constexpr (LDS_SCENE) {
-        int n_slot_words = sc.n_slots * sc.slot_f4;
-        int n_node_words = sc.n_nodes * 4;
-        stage_to_lds(smem, sc.slots, n_slot_words);
-        stage_to_lds(smem + n_slot_words, sc.nodes, n_node_words);
-        slots = smem;
-        nodes = smem + n_slot_words;
-        stack_base_f4 = smem + n_slot_words + n_node_words;
-        __syncthreads();
-    }
+    SceneView vw = global_view(sc);
+    f4 *free_lds = smem;
+    if constexpr (LDS_SCENE) free_lds = stage_scene(sc, smem, vw);
     using StackT = typename std::conditional<LDS_SCENE, short, int>::type;
-    StackT *stack = reinterpret_cast<StackT *>(stack_base_f4) + threadIdx.x;
+    StackT *stack = reinterpret_cast<StackT *>(free_lds) + threadIdx.x;
     const int stack_stride = blockDim.x;
 
     const int lane = threadIdx.x & 63;
     const unsigned long long lane_mask_lt = (1ull << lane) - 1ull;
-    const unsigned paths_per_block64 = 64u * (unsigned)rp.sample_count;
-
-    unsigned long long pool_next = 0, pool_end = 0;
-    bool exhausted = false;
+    WavePool wp;
+    pool_init(wp);
     bool alive = false;
     PathState ps;
     unsigned pixel = 0, sample = 0, n_rays = 0;
     Cnt<COUNT> cn;
 
     for (;;) {
-        // ---- hand new paths to idle lanes -------------------------------------------------
         unsigned long long need = __ballot(!alive);
         if (need != 0ull) {
-            if (pool_next >= pool_end && !exhausted) {
-                unsigned long long base = 0;
-                if (lane == 0) base = atomicAdd(rp.next_path, (unsigned long long)RT_POOL_CHUNK);
-                base = wave_bcast64(base);
-                if (base >= rp.n_paths) {
-                    exhausted = true;
-                } else {
-                    pool_next = base;
-                    pool_end = base + RT_POOL_CHUNK < rp.n_paths ? base + RT_POOL_CHUNK : rp.n_paths;
-                }
-            }
-            if (pool_next < pool_end) {
+            pool_refill(wp, rp, lane);
+            if (wp.k < wp.k_end) {
                 unsigned n_need = (unsigned)__popcll(need);
                 if (!alive) {
-                    unsigned rank = (unsigned)__popcll(need & lane_mask_lt);
-                    unsigned long long p = pool_next + rank;
-                    if (p < pool_end) {
-                        // path p -> (64-pixel strip, sample, pixel within the strip)
-                        unsigned long long blk = p / paths_per_block64;
-                        unsigned rem = (unsigned)(p - blk * paths_per_block64);
-                        unsigned s_local = rem >> 6;
-                        pixel = (unsigned)blk * 64u + (rem & 63u);
+                    unsigned k = wp.k + (unsigned)__popcll(need & lane_mask_lt);
+                    int px, py;
+                    unsigned pix, s_local;
+                    if (k < wp.k_end && pool_decode(wp, rp, k, pix, s_local, px, py)) {
+                        pixel = pix;
                         sample = s_local;
-                        if (pixel < (unsigned)rp.n_pixels) {
-                            ps = path_start(cam, rp.seed, pixel, (unsigned)rp.sample_begin + s_local);
-                            n_rays = 0;
-                            alive = true;
-                        }
+                        ps = path_start(cam, rp.seed, pixel, px, py, (unsigned)rp.sample_begin + s_local);
+                        n_rays = 0;
+                        alive = true;
                     }
                 }
-                pool_next = pool_next + n_need < pool_end ? pool_next + n_need : pool_end;
+                wp.k = wp.k + n_need < wp.k_end ? wp.k + n_need : wp.k_end;
             }
         }
         if (!__any(alive)) {
-            if (exhausted) break;
+            if (wp.exhausted && wp.k >= wp.k_end) break;
             continue;
         }
-
-        // ---- one segment of ray_color for every live lane -----------------------------------
         if (alive) {
-            bool cont = path_step<TRAV, COUNT, StackT>(sc, slots, nodes, cam, ps, stack, stack_stride, n_rays, cn);
+            bool cont = path_step<TRAV, COUNT, StackT>(sc, vw, cam, ps, stack, stack_stride, n_rays, cn);
             if (!cont) {
-                f4 rec;
-                rec.x = ps.L.x;
-                rec.y = ps.L.y;
-                rec.z = ps.L.z;
-                rec.w = __builtin_bit_cast(float, n_rays);
-                rp.stage[(size_t)sample * (size_t)rp.n_pixels + pixel] = rec;
+                write_record(rp, sample, pixel, ps.L, n_rays);
                 alive = false;
             }
         }
     }
     if constexpr (COUNT) flush_counters<COUNT>(rp.counters, cn);
+}
+
+// ------------------------------------------------------------------------------------------
+// BVH scenes: traversal and shading are decoupled (see the header comment).
+template <bool LDS_SCENE, bool COUNT>
+__global__ void __launch_bounds__(RT_MEGA_MAX_THREADS)
+render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
+    extern __shared__ f4 smem[];
+    SceneView vw = global_view(sc);
+    f4 *free_lds = smem;
+    if constexpr (LDS_SCENE) free_lds = stage_scene(sc, smem, vw);
+    using StackT = typename std::conditional<LDS_SCENE, short, int>::type;
+    StackT *stack = reinterpret_cast<StackT *>(free_lds) + threadIdx.x;
+    const int stack_stride = blockDim.x;
+
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lane_mask_lt = (1ull << lane) - 1ull;
+    const int min_ready = rp.min_ready;
+    const int leaf_min = rp.leaf_min;
+
+    enum { ST_IDLE = 0, ST_TRAV = 1, ST_READY = 2 };
+    WavePool wp;
+    pool_init(wp);
+    int state = ST_IDLE;
+    PathState ps;
+    Trav tv;
+    unsigned pixel = 0, sample = 0, n_rays = 0;
+    Cnt<COUNT> cn;
+    // wave-level schedule statistics (instrumented variant only), kept by lane 0
+    unsigned long long w_t_iters = 0, w_t_lanes = 0, w_l_iters = 0, w_l_lanes = 0, w_s_phases = 0, w_s_lanes = 0;
+
+    for (;;) {
+        if constexpr (COUNT) {
+            unsigned long long rm = __ballot(state == ST_READY);
+            if (rm) {
+                w_s_phases++;
+                w_s_lanes += __popcll(rm);
+            }
+        }
+        // ---- shade the lanes whose closest hit is known ---------------------------------------
+        if (state == ST_READY) {
+            TraceHit h;
+            h.t = tv.best_t;
+            h.slot = tv.best_slot;
+            bool cont = path_after_trace<COUNT>(sc, vw, cam, ps, h, cn);
+            if (cont) {
+                n_rays++;
+                trav_begin(tv, ps.ray, RT_INF);
+                state = ST_TRAV;
+            } else {
+                write_record(rp, sample, pixel, ps.L, n_rays);
+                state = ST_IDLE;
+            }
+        }
+        // ---- hand new paths to idle lanes -------------------------------------------------------
+        unsigned long long need = __ballot(state == ST_IDLE);
+        if (need != 0ull) {
+            pool_refill(wp, rp, lane);
+            if (wp.k < wp.k_end) {
+                unsigned n_need = (unsigned)__popcll(need);
+                if (state == ST_IDLE) {
+                    unsigned k = wp.k + (unsigned)__popcll(need & lane_mask_lt);
+                    int px, py;
+                    unsigned pix, s_local;
+                    if (k < wp.k_end && pool_decode(wp, rp, k, pix, s_local, px, py)) {
+                        pixel = pix;
+                        sample = s_local;
+                        ps = path_start(cam, rp.seed, pixel, px, py, (unsigned)rp.sample_begin + s_local);
+                        if (ps.depth > 0) {
+                            n_rays = 1;
+                            trav_begin(tv, ps.ray, RT_INF);
+                            state = ST_TRAV;
+                        } else { // max_depth 0: camera.h:141
+                            write_record(rp, sample, pixel, mk(0.0f, 0.0f, 0.0f), 0u);
+                        }
+                    }
+                }
+                wp.k = wp.k + n_need < wp.k_end ? wp.k + n_need : wp.k_end;
+            }
+        }
+        const bool pool_dry = wp.exhausted && wp.k >= wp.k_end;
+        if (!__any(state != ST_IDLE)) {
+            if (pool_dry) break;
+            continue;
+        }
+        // ---- traversal steps until enough lanes wait for shading ------------------------------
+        for (;;) {
+            unsigned long long tmask = __ballot(state == ST_TRAV);
+            if (tmask == 0ull) break;
+            unsigned long long rmask = __ballot(state == ST_READY || (state == ST_IDLE && !pool_dry));
+            if (__popcll(rmask) >= min_ready) break;
+            if constexpr (COUNT) {
+                unsigned long long im0 = __ballot(state == ST_TRAV && tv.ref >= 0);
+                if (im0) {
+                    w_t_iters++;
+                    w_t_lanes += __popcll(im0);
+                }
+            }
+            if (state == ST_TRAV && tv.ref >= 0)
+                trav_inner<COUNT, StackT>(tv, vw.nodes, 0.001f, stack, stack_stride, cn);
+            bool at_leaf = state == ST_TRAV && tv.ref < 0 && tv.ref != RT_TRAV_DONE;
+            unsigned long long lmask = __ballot(at_leaf);
+            if (lmask != 0ull) {
+                unsigned long long imask = __ballot(state == ST_TRAV && tv.ref >= 0);
+                if (__popcll(lmask) >= leaf_min || imask == 0ull) {
+                    if constexpr (COUNT) {
+                        w_l_iters++;
+                        w_l_lanes += __popcll(lmask);
+                    }
+                    if (at_leaf) {
+                        trav_test_leaf<COUNT>(tv, tv.ref, sc, vw, ps.ray, 0.001f, cn);
+                        trav_pop(tv, stack, stack_stride);
+                    }
+                }
+            }
+            if (state == ST_TRAV && tv.ref == RT_TRAV_DONE) state = ST_READY;
+        }
+    }
+    if constexpr (COUNT) {
+        flush_counters<COUNT>(rp.counters, cn);
+        if (lane == 0) {
+            atomicAdd(&rp.counters->sched[0], w_t_iters);
+            atomicAdd(&rp.counters->sched[1], w_t_lanes);
+            atomicAdd(&rp.counters->sched[2], w_l_iters);
+            atomicAdd(&rp.counters->sched[3], w_l_lanes);
+            atomicAdd(&rp.counters->sched[4], w_s_phases);
+            atomicAdd(&rp.counters->sched[5], w_s_lanes);
+        }
+    }
 }
 
 // accum[pixel] += sum over the launch's samples, in sample order; ray counts are
@@ -169,6 +357,7 @@ __global__ void __launch_bounds__(RT_TRACE_THREADS)
 trace_batch(DevScene sc, const rt_ray *rays, long long n_rays, float tmin, float tmax, rt_hit *hits) {
     __shared__ int stack_mem[RT_STACK_DEPTH * RT_TRACE_THREADS];
     int *stack = stack_mem + threadIdx.x;
+    const SceneView vw = global_view(sc);
     Cnt<false> cn;
     for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < n_rays;
          k += (long long)gridDim.x * blockDim.x) {
@@ -179,10 +368,9 @@ trace_batch(DevScene sc, const rt_ray *rays, long long n_rays, float tmin, float
         r.tm = in.tm;
         TraceHit h;
         if constexpr (TRAV == TRAV_LINEAR)
-            h = trace_linear<false>(sc, sc.slots, sc.meta, r, tmin, tmax, cn);
+            h = trace_linear<false>(sc, vw, r, tmin, tmax, cn);
         else
-            h = trace_bvh<false, int>(sc, sc.slots, sc.nodes, sc.meta, r, tmin, tmax, stack, RT_TRACE_THREADS,
-                                      cn);
+            h = trace_bvh<false, int>(sc, vw, r, tmin, tmax, stack, RT_TRACE_THREADS, cn);
         rt_hit out;
         out.prim = -1;
         out.front_face = 0;
@@ -191,8 +379,8 @@ trace_batch(DevScene sc, const rt_ray *rays, long long n_rays, float tmin, float
         out.normal[0] = out.normal[1] = out.normal[2] = 0.0f;
         out.u = out.v = 0.0f;
         if (h.slot >= 0) {
-            Surf s = surface_at(sc, sc.slots, sc.meta, r, h);
-            out.prim = s.prim;
+            Surf s = surface_at(sc, vw, r, h);
+            out.prim = s.rec.w;
             out.front_face = s.front ? 1 : 0;
             out.t = h.t;
             out.p[0] = s.p.x;
@@ -201,8 +389,9 @@ trace_batch(DevScene sc, const rt_ray *rays, long long n_rays, float tmin, float
             out.normal[0] = s.n.x;
             out.normal[1] = s.n.y;
             out.normal[2] = s.n.z;
-            if (s.type == RT_PRIM_SPHERE) sphere_uv(s.outward, out.u, out.v); // sphere.h:70
-            else {
+            if (RT_KIND_PRIM(s.rec.x) == RT_PRIM_SPHERE) { // sphere.h:70
+                sphere_uv(s.outward, out.u, out.v);
+            } else {
                 out.u = s.u;
                 out.v = s.v;
             }
@@ -229,13 +418,28 @@ static hipError_t launch_mega_tc(const DevScene &sc, const DevCamera &cam, const
     return hipGetLastError();
 }
 
+template <bool LDS_SCENE>
+static hipError_t launch_mega_bvh_tc(const DevScene &sc, const DevCamera &cam, const RenderParams &rp,
+                                     const LaunchGeom &lg, hipStream_t stream) {
+    if (rp.counters)
+        hipLaunchKernelGGL((render_mega_bvh<LDS_SCENE, true>), dim3(lg.grid), dim3(lg.block), lg.lds_bytes,
+                           stream, sc, cam, rp);
+    else
+        hipLaunchKernelGGL((render_mega_bvh<LDS_SCENE, false>), dim3(lg.grid), dim3(lg.block), lg.lds_bytes,
+                           stream, sc, cam, rp);
+    return hipGetLastError();
+}
+
 hipError_t launch_mega(const DevScene &sc, const DevCamera &cam, const RenderParams &rp, const LaunchGeom &lg,
                        hipStream_t stream) {
     if (sc.traversal == TRAV_LINEAR)
         return lg.lds_scene ? launch_mega_tc<TRAV_LINEAR, true>(sc, cam, rp, lg, stream)
                             : launch_mega_tc<TRAV_LINEAR, false>(sc, cam, rp, lg, stream);
-    return lg.lds_scene ? launch_mega_tc<TRAV_BVH, true>(sc, cam, rp, lg, stream)
-                        : launch_mega_tc<TRAV_BVH, false>(sc, cam, rp, lg, stream);
+    if (rp.scheduler == 0)
+        return lg.lds_scene ? launch_mega_tc<TRAV_BVH, true>(sc, cam, rp, lg, stream)
+                            : launch_mega_tc<TRAV_BVH, false>(sc, cam, rp, lg, stream);
+    return lg.lds_scene ? launch_mega_bvh_tc<true>(sc, cam, rp, lg, stream)
+                        : launch_mega_bvh_tc<false>(sc, cam, rp, lg, stream);
 }
 
 hipError_t set_mega_lds_limit(int bytes) {
@@ -253,6 +457,15 @@ hipError_t set_mega_lds_limit(int bytes) {
     RT_SET(TRAV_BVH, false, true)
     RT_SET(TRAV_BVH, false, false)
 #undef RT_SET
+#define RT_SET2(L, C)                                                                                        \
+    if (e == hipSuccess)                                                                                     \
+        e = hipFuncSetAttribute((const void *)render_mega_bvh<L, C>,                                         \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    RT_SET2(true, true)
+    RT_SET2(true, false)
+    RT_SET2(false, true)
+    RT_SET2(false, false)
+#undef RT_SET2
     return e;
 }
 

@@ -7,17 +7,21 @@
 
 #define RT_MEGA_MAX_THREADS 1024
 #define RT_TRACE_THREADS 256
-#define RT_POOL_CHUNK 256ull // paths a wave reserves from the global counter at a time
+#define RT_POOL_SAMPLES 4u // a wave reserves 64 pixels x this many samples from the global counter
 
 struct RenderParams {
     int width, height, n_pixels;
     int sample_begin; // global index of the first sample of this launch
     int sample_count; // samples per pixel in this launch
     uint32_t seed;
-    unsigned long long n_paths;    // ceil(n_pixels/64) * 64 * sample_count (64-pixel strips)
+    unsigned n_sample_groups;      // ceil(sample_count / RT_POOL_SAMPLES)
+    unsigned n_chunks;             // ceil(n_pixels / 64) * n_sample_groups
     rtc::f4 *stage;                // [sample_count][n_pixels] {r g b rays}
-    unsigned long long *next_path; // pool counter, zeroed before the launch
+    unsigned *next_chunk;          // pool counter, zeroed before the launch
     rtc::Counters *counters;       // non-null: count tests (instrumented kernel variant)
+    int scheduler; // BVH scenes: 0 = one whole ray per wave iteration, 1 = decoupled traverse / shade
+    int min_ready; // decoupled: lanes that must wait for shading before traversal is interrupted
+    int leaf_min;  // decoupled: lanes that must wait at a leaf before the leaf block runs
 };
 
 struct LaunchGeom {

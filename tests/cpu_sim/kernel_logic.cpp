@@ -16,8 +16,6 @@ using namespace rtc;
 
 struct SimScene {
     rtf::HostScene hs;
-    std::vector<rt_material> mats;
-    std::vector<rt_texture> texs;
     std::vector<rt_perlin> perl;
     std::vector<rt_image> imgs;
     std::vector<uint8_t> texels;
@@ -33,20 +31,19 @@ void *sim_scene_create(const rt_scene_desc *d, uint32_t flags) {
         delete s;
         return nullptr;
     }
-    s->mats.assign(d->materials, d->materials + d->n_materials);
-    s->texs.assign(d->textures, d->textures + d->n_textures);
     s->perl.assign(d->perlins, d->perlins + d->n_perlins);
     s->imgs.assign(d->images, d->images + d->n_images);
     s->texels.assign(d->texels, d->texels + d->n_texel_bytes);
     DevScene &dv = s->dev;
     memset(&dv, 0, sizeof(dv));
     dv.slots = s->hs.slots.data();
-    dv.meta = s->hs.meta.data();
+    dv.rec_i = s->hs.rec_i.data();
+    dv.rec_f = s->hs.rec_f.data();
+    dv.textures = s->hs.textures.data();
+    dv.n_textures = (int)s->hs.textures.size();
     dv.nodes = s->hs.nodes.data();
     dv.xf = s->hs.xf.data();
     dv.chain_first = s->hs.chain_first.data();
-    dv.materials = s->mats.data();
-    dv.textures = s->texs.data();
     dv.perlins = s->perl.data();
     dv.images = s->imgs.data();
     dv.texels = s->texels.data();
@@ -66,6 +63,7 @@ void sim_trace_batch(void *scene, const rt_ray *rays, long long n, float tmin, f
                      unsigned long long *box_tests, unsigned long long *prim_tests) {
     SimScene *s = (SimScene *)scene;
     const DevScene &sc = s->dev;
+    const SceneView vw = global_view(sc);
     int stack[RT_STACK_DEPTH + 8];
     Cnt<true> cn;
     for (long long k = 0; k < n; k++) {
@@ -73,20 +71,19 @@ void sim_trace_batch(void *scene, const rt_ray *rays, long long n, float tmin, f
         r.o = mk(rays[k].orig[0], rays[k].orig[1], rays[k].orig[2]);
         r.d = mk(rays[k].dir[0], rays[k].dir[1], rays[k].dir[2]);
         r.tm = rays[k].tm;
-        TraceHit h = sc.traversal == TRAV_LINEAR
-                         ? trace_linear<true>(sc, sc.slots, sc.meta, r, tmin, tmax, cn)
-                         : trace_bvh<true, int>(sc, sc.slots, sc.nodes, sc.meta, r, tmin, tmax, stack, 1, cn);
+        TraceHit h = sc.traversal == TRAV_LINEAR ? trace_linear<true>(sc, vw, r, tmin, tmax, cn)
+                                                 : trace_bvh<true, int>(sc, vw, r, tmin, tmax, stack, 1, cn);
         rt_hit out;
         memset(&out, 0, sizeof(out));
         out.prim = -1;
         if (h.slot >= 0) {
-            Surf sf = surface_at(sc, sc.slots, sc.meta, r, h);
-            out.prim = sf.prim;
+            Surf sf = surface_at(sc, vw, r, h);
+            out.prim = sf.rec.w;
             out.front_face = sf.front ? 1 : 0;
             out.t = h.t;
             out.p[0] = sf.p.x; out.p[1] = sf.p.y; out.p[2] = sf.p.z;
             out.normal[0] = sf.n.x; out.normal[1] = sf.n.y; out.normal[2] = sf.n.z;
-            if (sf.type == RT_PRIM_SPHERE) sphere_uv(sf.outward, out.u, out.v);
+            if (RT_KIND_PRIM(sf.rec.x) == RT_PRIM_SPHERE) sphere_uv(sf.outward, out.u, out.v);
             else { out.u = sf.u; out.v = sf.v; }
         }
         hits[k] = out;
@@ -105,6 +102,7 @@ void sim_render(void *scene, const rt_camera_desc *cam, int sample_begin, int sa
     for (int k = 0; k < 3; k++) dc.background[k] = cam->background[k];
     dc.defocus_angle = cam->defocus_angle;
     dc.max_depth = cam->max_depth;
+    const SceneView vw = global_view(sc);
     int stack[RT_STACK_DEPTH + 8];
     Cnt<false> cn;
     unsigned long long rays = 0;
@@ -112,12 +110,13 @@ void sim_render(void *scene, const rt_camera_desc *cam, int sample_begin, int sa
     for (int pix = 0; pix < npix; pix++) {
         float r = 0, g = 0, b = 0;
         for (int sidx = 0; sidx < sample_count; sidx++) {
-            PathState ps = path_start(dc, seed, (unsigned)pix, (unsigned)(sample_begin + sidx));
+            PathState ps = path_start(dc, seed, (unsigned)pix, pix % dc.f.image_width, pix / dc.f.image_width,
+                                      (unsigned)(sample_begin + sidx));
             unsigned n_rays = 0;
             for (;;) {
                 bool cont = sc.traversal == TRAV_LINEAR
-                                ? path_step<TRAV_LINEAR, false, int>(sc, sc.slots, sc.nodes, dc, ps, stack, 1, n_rays, cn)
-                                : path_step<TRAV_BVH, false, int>(sc, sc.slots, sc.nodes, dc, ps, stack, 1, n_rays, cn);
+                                ? path_step<TRAV_LINEAR, false, int>(sc, vw, dc, ps, stack, 1, n_rays, cn)
+                                : path_step<TRAV_BVH, false, int>(sc, vw, dc, ps, stack, 1, n_rays, cn);
                 if (!cont) break;
             }
             rays += n_rays;

@@ -1,0 +1,13 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from raytracing_amd import abi, binding
+G = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+scene = sys.argv[1] if len(sys.argv) > 1 else "bouncing_spheres"
+arrays = abi.SceneArrays.load(f"{G}/{scene}.rtscene"); cam, _ = abi.load_camera_file(f"{G}/{scene}.cam")
+sc = binding.Scene(arrays)
+acc, st = sc.render(cam, 100, counters=True)
+s = list(st.sched)
+w = st.rays / 64
+print(f"rays {st.rays} box/ray {st.box_tests/st.rays:.1f} prim/ray {(st.sphere_tests+st.quad_tests)/st.rays:.2f} kernel_ms {st.kernel_ms:.3f}")
+if s[0]:
+    print(f"inner blocks {s[0]} ({s[0]/w:.1f} per 64 rays) active {s[1]/s[0]:.1f}/64 | leaf blocks {s[2]} ({s[2]/w:.1f} per 64 rays) active {s[3]/max(s[2],1):.1f}/64 | shade phases {s[4]} ({s[4]/w:.2f} per 64 rays) lanes {s[5]/max(s[4],1):.1f}/64")
