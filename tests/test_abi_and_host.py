@@ -1,0 +1,176 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol the header declares, the
+host half (camera, tonemap, scene files, error paths) behaves like the reference, and the
+kernel sources' per-ray logic (compiled for the host by tests/cpu_sim, test-only) agrees with
+the oracle.  No GPU compute is called here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from raytracing_amd import abi, binding
+from tests import oracle_lib as O, sim_lib as S
+from tests.conftest import GOLDEN, ROOT, SCENES, load_scene
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "rt_amd.h")).read()
+    declared = set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no prototypes found in rt_amd.h"
+    L = binding.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), f"librt_amd.so does not export {name}"
+    assert declared == set(binding.EXPORTS)
+    assert L.rt_abi_version() == abi.RT_AMD_ABI_VERSION
+
+
+def test_struct_sizes_match_header():
+    # sizes the C compiler gives the structs (checked when the oracle / sim were compiled) are
+    # mirrored by ctypes; the fixture files written by C code parse with these layouts
+    assert C.sizeof(abi.CameraDesc) == 76 and C.sizeof(abi.CameraFrame) == 120
+    assert C.sizeof(abi.RenderOpts) == 32
+    arrays, cam, frame = load_scene("bouncing_spheres")
+    assert len(arrays.prims) == 485 and cam.image_width == 400 and frame.image_height == 225
+
+
+@pytest.mark.parametrize("scene", SCENES)
+def test_library_camera_initialize_matches_reference(scene):
+    arrays, cam, ref_frame = load_scene(scene)
+    assert bytes(binding.camera_initialize(cam)) == bytes(ref_frame)
+
+
+def test_camera_argument_errors():
+    cam = abi.CameraDesc()
+    with pytest.raises(binding.RtError) as e:
+        binding.camera_initialize(cam)  # image_width 0
+    assert e.value.code == abi.RT_ERR_ARG
+
+
+def test_tonemap_matches_write_color():
+    rng = np.random.default_rng(0)
+    acc = rng.uniform(-0.5, 3.0, size=(64, 64, 3)).astype(np.float32)
+    acc[0, 0] = (0, 1.0, 0.25)
+    a = binding.tonemap_u8(acc, 0.5)
+    assert np.array_equal(a, O.tonemap_u8(acc, 0.5))
+    assert a[0, 0].tolist() == [0, int(256 * np.float32(np.sqrt(np.float32(0.5)))), int(256 * np.sqrt(0.125))]
+    assert a.max() == 255  # 0.999 * 256 = 255.7
+
+
+def test_scene_file_roundtrip(tmp_path):
+    arrays, cam, _ = load_scene("cornell_box")
+    p = str(tmp_path / "x.rtscene")
+    d = arrays.desc()
+    binding.check(binding.lib().rt_scene_file_save(C.byref(d), p.encode()))
+    assert open(p, "rb").read() == open(os.path.join(GOLDEN, "cornell_box.rtscene"), "rb").read()
+    out = C.POINTER(abi.SceneDesc)()
+    binding.check(binding.lib().rt_scene_file_load(p.encode(), C.byref(out)))
+    assert out.contents.n_prims == 18 and out.contents.n_chains == 2
+    binding.lib().rt_scene_file_free(out)
+    assert binding.lib().rt_scene_file_load(b"/nonexistent", C.byref(out)) == abi.RT_ERR_IO
+    back = abi.SceneArrays.load(p)
+    assert back.prims.tobytes() == arrays.prims.tobytes()
+
+
+def test_no_gpu_means_loud_failure():
+    """The product has no CPU path: without a device, scene creation fails with RT_ERR_HIP."""
+    if binding.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    arrays, cam, _ = load_scene("quads")
+    with pytest.raises(binding.RtError) as e:
+        binding.Scene(arrays)
+    assert e.value.code == abi.RT_ERR_HIP
+
+
+def test_descriptor_validation():
+    arrays, cam, _ = load_scene("quads")
+    bad = abi.SceneArrays(prims=arrays.prims.copy(), materials=arrays.materials, textures=arrays.textures)
+    bad.prims["material"][2] = 99
+    with pytest.raises(binding.RtError) as e:
+        binding.Scene(bad)
+    assert e.value.code == abi.RT_ERR_ARG and "material" in str(e.value)
+
+
+# ---- kernel logic on the host (same headers the HIP kernels are built from) -------------------
+
+@pytest.mark.parametrize("scene", SCENES)
+def test_kernel_logic_matches_reference_records(scene):
+    arrays, cam, _ = load_scene(scene)
+    rays, ref_hits, tmin, tmax = O.load_rays_file(os.path.join(GOLDEN, scene + ".rays"))
+    for flags in (0, abi.RT_SCENE_FORCE_LINEAR) + ((abi.RT_SCENE_FORCE_BVH,) if scene != "cornell_box" else ()):
+        hits, _, _ = S.SimScene(arrays, flags).trace(rays, tmin, tmax)
+        assert hits.tobytes() == ref_hits.tobytes(), f"flags {flags}"
+
+
+def test_kernel_logic_bvh_never_drops_a_hit():
+    arrays, cam, _ = load_scene("bouncing_spheres")
+    rng = np.random.default_rng(3)
+    n = 200_000
+    rays = np.zeros(n, abi.RAY_DT)
+    o = rng.normal(size=(n, 3))
+    o /= np.linalg.norm(o, axis=1, keepdims=True)
+    o *= rng.uniform(5, 60, size=(n, 1))
+    o[:, 1] = np.abs(o[:, 1]) * 0.3 + 0.05
+    tgt = np.stack([rng.uniform(-11, 11, n), rng.uniform(0, 1.0, n), rng.uniform(-11, 11, n)], 1)
+    rays["orig"], rays["dir"], rays["tm"] = o, (tgt - o) * rng.uniform(0.2, 3, size=(n, 1)), rng.uniform(0, 1, n)
+    # axis-parallel rays (zero direction components) exercise the guarded reciprocal
+    rays["dir"][:1000, 0] = 0
+    rays["dir"][1000:2000, 1] = 0
+    rays["dir"][2000:2500, [0, 2]] = 0
+    sim = S.SimScene(arrays)
+    assert sim.n_nodes == 484 and sim.depth <= 30
+    hits, box, prim = sim.trace(rays)
+    ref, _ = O.OracleScene(arrays).trace(rays, 0.001, np.inf, O.TRACE_BAKED)  # scan of all 485
+    assert np.array_equal(hits["prim"], ref["prim"]) and np.array_equal(hits["t"], ref["t"])
+    assert prim / n < 5  # the tree culls: a handful of exact tests per ray instead of 485
+
+
+def test_kernel_logic_tie_rules():
+    """Coincident primitives: the winner is the one the reference's sequential scan keeps
+    (a later quad replaces, a later sphere does not), whatever order the tree visits them in."""
+    mats = np.zeros(1, abi.MATERIAL_DT)
+    mats["texture"] = 0
+    tex = np.zeros(1, abi.TEXTURE_DT)
+    rng = np.random.default_rng(5)
+    for trial in range(20):
+        n = 40
+        prims = np.zeros(n, abi.PRIM_DT)
+        prims["xform"] = -1
+        kinds = rng.integers(0, 2, n)
+        for i in range(n):
+            if kinds[i]:  # one of 4 distinct quads, many duplicates
+                k = rng.integers(0, 4)
+                prims[i]["type"] = abi.RT_PRIM_QUAD
+                prims[i]["a"], prims[i]["b"], prims[i]["c"] = (-2, -2, float(k)), (4, 0, 0), (0, 4, 0)
+            else:
+                k = rng.integers(0, 4)
+                prims[i]["type"] = abi.RT_PRIM_SPHERE
+                prims[i]["a"], prims[i]["c"] = (0, 0, float(k) + 10), (1.0, 0, 0)
+        arrays = abi.SceneArrays(prims=prims, materials=mats, textures=tex)
+        rays = np.zeros(64, abi.RAY_DT)
+        rays["orig"] = np.c_[rng.uniform(-1, 1, 64), rng.uniform(-1, 1, 64), np.full(64, 20.0)]
+        rays["dir"] = (0, 0, -1)
+        ref, _ = O.OracleScene(arrays).trace(rays, 0.001, np.inf, O.TRACE_REFERENCE)
+        for flags in (abi.RT_SCENE_FORCE_BVH, abi.RT_SCENE_FORCE_LINEAR):
+            hits, _, _ = S.SimScene(arrays, flags).trace(rays)
+            assert np.array_equal(hits["prim"], ref["prim"]) and np.array_equal(hits["t"], ref["t"])
+
+
+def test_kernel_logic_render_matches_oracle():
+    for scene in ("bouncing_spheres", "cornell_box", "perlin_spheres", "earth"):
+        arrays, cam, _ = load_scene(scene)
+        cam.image_width = 48
+        acc, rays = S.SimScene(arrays).render(cam, 2, seed=3)
+        ref, st = O.OracleScene(arrays).render(cam, 2, sampler=O.SAMPLER_CB, trace_mode=O.TRACE_REFERENCE, seed=3)
+        assert rays == st.rays
+        assert np.allclose(acc, ref, rtol=2e-6, atol=1e-7)
+
+
+def test_empty_and_degenerate_scenes():
+    arrays = abi.SceneArrays()
+    rays = np.zeros(4, abi.RAY_DT)
+    rays["dir"] = (0, 0, -1)
+    hits, _, _ = S.SimScene(arrays).trace(rays)
+    assert (hits["prim"] == -1).all()
+    h2, _ = O.OracleScene(arrays).trace(rays)
+    assert (h2["prim"] == -1).all()
