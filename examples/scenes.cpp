@@ -1,0 +1,226 @@
+// scenes.cpp — the benchmark scenes, written against the drop-in scene API
+// (raytracing_amd/dropin), rendered by librt_amd.so.
+//
+//   rt_scenes <scene> [--spp N] [--width W] [--depth D] [--out file.png] [--dump file.rtscene]
+//
+// The seven scenes restate the reference's main.cpp:14-288 as data; `synth1m` is the
+// 1 000 001-primitive stress scene (no counterpart in the reference).  Random numbers that
+// the reference draws inside one argument list are drawn here one statement at a time, in
+// the order the reference's toolchain (g++) evaluates them, so that the scenes are the same
+// under any compiler; tests/test_dropin.py checks the result against the reference's dump.
+#include "camera.h"
+#include "bvh.h"
+#include "hittable_list.h"
+#include "material.h"
+#include "quad.h"
+#include "sphere.h"
+#include "texture.h"
+
+#include <cstring>
+
+struct View {
+    float aspect;
+    int width, spp;
+    color background;
+    float vfov;
+    point3 from, at;
+    float defocus_angle, focus_dist;
+};
+
+static int g_spp = -1, g_width = -1, g_depth = 50;
+static const char *g_out = "RayTracing.png";
+
+static void shoot(const hittable &world, const View &v) {
+    camera cam;
+    cam.aspect_ratio = v.aspect;
+    cam.image_width = g_width > 0 ? g_width : v.width;
+    cam.samples_per_pixel = g_spp > 0 ? g_spp : v.spp;
+    cam.max_depth = g_depth;
+    cam.background = v.background;
+    cam.vfov = v.vfov;
+    cam.lookfrom = v.from;
+    cam.lookat = v.at;
+    cam.vup = vec3(0.0f, 1.0f, 0.0f);
+    cam.defocus_angle = v.defocus_angle;
+    cam.focus_dist = v.focus_dist;
+    cam.render(world, g_out);
+    const rt_render_stats &s = cam.last_stats;
+    if (s.paths)
+        fprintf(stderr, "%llu paths, %llu rays, render kernel %.3f ms (%.1f Mpaths/s, %.1f Mrays/s)\n",
+                (unsigned long long)s.paths, (unsigned long long)s.rays, s.kernel_ms,
+                s.paths / s.kernel_ms * 1e-3, s.rays / s.kernel_ms * 1e-3);
+}
+
+static const color kSky(0.7f, 0.8f, 1.0f), kBlack(0.0f, 0.0f, 0.0f);
+static const float kWide = 16.0f / 9.0f;
+
+static shared_ptr<texture> ground_checker() {
+    return make_shared<checker_texture>(0.32f, color(0.2f, 0.3f, 0.1f), color(0.9f, 0.9f, 0.9f));
+}
+
+static void bouncing_spheres() {
+    hittable_list world;
+    world.add(make_shared<sphere>(point3(0.0f, -1000.0f, 0.0f), 1000.0f, make_shared<lambertian>(ground_checker())));
+    for (int a = -11; a < 11; a++)
+        for (int b = -11; b < 11; b++) {
+            float choose_mat = random_float();
+            float jz = random_float(); // the z jitter is drawn before the x jitter
+            float jx = random_float();
+            point3 center(a + 0.9f * jx, 0.2f, b + 0.9f * jz);
+            if (!((center - point3(4.0f, 0.2f, 0.0f)).length() > 0.9f)) continue;
+            if (choose_mat < 0.8f) {
+                color second = color::random(); // right operand of the product first
+                color first = color::random();
+                auto mat = make_shared<lambertian>(first * second);
+                point3 center2 = center + vec3(0.0f, random_float(0.0f, 0.5f), 0.0f);
+                world.add(make_shared<sphere>(center, center2, 0.2f, mat));
+            } else if (choose_mat < 0.95) {
+                color albedo = color::random(0.5f, 1.0f);
+                float fuzz = random_float(0.0f, 0.5f);
+                world.add(make_shared<sphere>(center, 0.2f, make_shared<metal>(albedo, fuzz)));
+            } else {
+                world.add(make_shared<sphere>(center, 0.2f, make_shared<dielectric>(1.5f)));
+            }
+        }
+    world.add(make_shared<sphere>(point3(0.0f, 1.0f, 0.0f), 1.0f, make_shared<dielectric>(1.5f)));
+    world.add(make_shared<sphere>(point3(-4.0f, 1.0f, 0.0f), 1.0f, make_shared<lambertian>(color(0.4f, 0.2f, 0.1f))));
+    world.add(make_shared<sphere>(point3(4.0f, 1.0f, 0.0f), 1.0f, make_shared<metal>(color(0.7f, 0.6f, 0.5f), 0.0f)));
+    world = hittable_list(make_shared<bvh_node>(world));
+    shoot(world, View{kWide, 400, 10, kSky, 20.0f, point3(13.0f, 2.0f, 3.0f), point3(0.0f, 0.0f, -1.0f), 0.6f, 10.0f});
+}
+
+static void checkered_spheres() {
+    hittable_list world;
+    auto checker = ground_checker();
+    world.add(make_shared<sphere>(point3(0.0f, -10.0f, 0.0f), 10.0f, make_shared<lambertian>(checker)));
+    world.add(make_shared<sphere>(point3(0.0f, 10.0f, 0.0f), 10.0f, make_shared<lambertian>(checker)));
+    shoot(world, View{kWide, 400, 10, kSky, 20.0f, point3(13.0f, 2.0f, 3.0f), point3(0.0f, 0.0f, 0.0f), 0.0f, 10.0f});
+}
+
+static void earth() {
+    auto surface = make_shared<lambertian>(make_shared<image_texture>("earthmap.jpg"));
+    auto globe = make_shared<sphere>(point3(0.0f, 0.0f, 0.0f), 2.0f, surface);
+    shoot(hittable_list(globe), View{kWide, 400, 100, kSky, 20.0f, point3(0.0f, 0.0f, 12.0f), point3(0.0f, 0.0f, 0.0f), 0.0f, 10.0f});
+}
+
+static void perlin_spheres() {
+    hittable_list world;
+    auto marble = make_shared<noise_texture>(4);
+    world.add(make_shared<sphere>(point3(0.0f, -1000.0f, 0.0f), 1000.0f, make_shared<lambertian>(marble)));
+    world.add(make_shared<sphere>(point3(0.0f, 2.0f, 0.0f), 2.0f, make_shared<lambertian>(marble)));
+    shoot(world, View{kWide, 400, 100, kSky, 20.0f, point3(13.0f, 2.0f, 3.0f), point3(0.0f, 0.0f, 0.0f), 0.0f, 10.0f});
+}
+
+static void quads() {
+    hittable_list world;
+    const struct {
+        point3 Q;
+        vec3 u, v;
+        color c;
+    } q[5] = {{point3(-3, -2, 5), vec3(0, 0, -4), vec3(0, 4, 0), color(1.0f, 0.2f, 0.2f)},
+              {point3(-2, -2, 0), vec3(4, 0, 0), vec3(0, 4, 0), color(0.2f, 1.0f, 0.2f)},
+              {point3(3, -2, 1), vec3(0, 0, 4), vec3(0, 4, 0), color(0.2f, 0.2f, 1.0f)},
+              {point3(-2, 3, 1), vec3(4, 0, 0), vec3(0, 0, 4), color(1.0f, 0.5f, 0.0f)},
+              {point3(-2, -3, 5), vec3(4, 0, 0), vec3(0, 0, -4), color(0.2f, 0.8f, 0.8f)}};
+    std::vector<shared_ptr<material>> mats;
+    for (const auto &e : q) mats.push_back(make_shared<lambertian>(e.c)); // all materials first, as the reference
+    for (int i = 0; i < 5; i++) world.add(make_shared<quad>(q[i].Q, q[i].u, q[i].v, mats[i]));
+    shoot(world, View{1.0f, 400, 100, kSky, 80.0f, point3(0.0f, 0.0f, 9.0f), point3(0.0f, 0.0f, 0.0f), 0.0f, 10.0f});
+}
+
+static void simple_light() {
+    hittable_list world;
+    auto marble = make_shared<noise_texture>(4.0f);
+    world.add(make_shared<sphere>(point3(0.0f, -1000.0f, 0.0f), 1000.0f, make_shared<lambertian>(marble)));
+    world.add(make_shared<sphere>(point3(0.0f, 2.0f, 0.0f), 2.0f, make_shared<lambertian>(marble)));
+    auto lamp = make_shared<diffuse_light>(color(4.0f, 4.0f, 4.0f));
+    world.add(make_shared<quad>(point3(3.0f, 1.0f, -2.0f), vec3(2.0f, 0.0f, 0.0f), vec3(0.0f, 2.0f, 0.0f), lamp));
+    world.add(make_shared<sphere>(point3(0.0f, 7.0f, 0.0f), 2.0f, lamp));
+    shoot(world, View{kWide, 400, 100, kBlack, 20.0f, point3(26.0f, 3.0f, 6.0f), point3(0.0f, 2.0f, 0.0f), 0.0f, 10.0f});
+}
+
+static void cornell_box() {
+    hittable_list world;
+    auto red = make_shared<lambertian>(color(0.65f, 0.05f, 0.05f));
+    auto white = make_shared<lambertian>(color(0.73, 0.73, 0.73));
+    auto green = make_shared<lambertian>(color(0.12, 0.45, 0.15));
+    auto lamp = make_shared<diffuse_light>(color(15.0f, 15.0f, 15.0f));
+    const float s = 555.0f;
+    world.add(make_shared<quad>(point3(s, 0, 0), vec3(0, s, 0), vec3(0, 0, s), green));
+    world.add(make_shared<quad>(point3(0, 0, 0), vec3(0, s, 0), vec3(0, 0, s), red));
+    world.add(make_shared<quad>(point3(343.0f, 554.0f, 332.0f), vec3(-130.0f, 0, 0), vec3(0, 0, -105.0f), lamp));
+    world.add(make_shared<quad>(point3(0, 0, 0), vec3(s, 0, 0), vec3(0, 0, s), white));
+    world.add(make_shared<quad>(point3(s, s, s), vec3(-s, 0, 0), vec3(0, 0, -s), white));
+    world.add(make_shared<quad>(point3(0, 0, s), vec3(s, 0, 0), vec3(0, s, 0), white));
+    shared_ptr<hittable> tall = box(point3(0, 0, 0), point3(165.0f, 330.0f, 165.0f), white);
+    tall = make_shared<translate>(make_shared<rotate_xyz>(tall, 0.0f, 15.0f, 0.0f), vec3(265.0f, 0.0f, 295.0f));
+    world.add(tall);
+    shared_ptr<hittable> cube = box(point3(0, 0, 0), point3(165.0f, 165.0f, 165.0f), white);
+    cube = make_shared<translate>(make_shared<rotate_xyz>(cube, -15.0f, -18.0f, 0.0f), vec3(130.0f, 0.0f, 65.0f));
+    world.add(make_shared<scaling>(cube, vec3(0.5f, 0.5f, 0.5f)));
+    shoot(world, View{1.0f, 600, 10, kBlack, 40.0f, point3(278.0f, 278.0f, -800.0f), point3(278.0f, 278.0f, 0.0f), 0.0f, 10.0f});
+}
+
+// 10^6 cells on a grid, one sphere or quad per cell, plus the ground: splitmix64 keyed layout,
+// twelve draws per cell whether they are used or not.
+static void synth1m(int half) {
+    uint64_t state = 0x5EED1234ull;
+    auto u01 = [&]() {
+        uint64_t z = (state += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        return float(z >> 40) * (1.0f / 16777216.0f);
+    };
+    hittable_list world;
+    world.add(make_shared<sphere>(point3(0.0f, -10000.0f, 0.0f), 10000.0f, make_shared<lambertian>(ground_checker())));
+    for (int a = -half; a < half; a++)
+        for (int b = -half; b < half; b++) {
+            float kind = u01(), choose = u01(), jx = u01(), jz = u01(), rr = u01();
+            float c0 = u01(), c1 = u01(), c2 = u01(), f = u01(), q0 = u01(), q1 = u01(), q2 = u01();
+            float r = 0.1f + 0.15f * rr;
+            point3 base(a + 0.9f * jx, 0.0f, b + 0.9f * jz);
+            shared_ptr<material> mat;
+            if (choose < 0.8f) mat = make_shared<lambertian>(color(c0 * c0, c1 * c1, c2 * c2));
+            else if (choose < 0.95f) mat = make_shared<metal>(color(0.5f + 0.5f * c0, 0.5f + 0.5f * c1, 0.5f + 0.5f * c2), 0.5f * f);
+            else if (choose < 0.99f) mat = make_shared<dielectric>(1.5f);
+            else mat = make_shared<diffuse_light>(color(4.0f * c0, 4.0f * c1, 4.0f * c2));
+            if (kind < 0.75f)
+                world.add(make_shared<sphere>(base + vec3(0.0f, r, 0.0f), r, mat));
+            else
+                world.add(make_shared<quad>(base, vec3(0.4f * (q0 - 0.5f), 0.0f, 0.4f * (q1 - 0.5f) + 0.2f),
+                                            vec3(0.1f * (q2 - 0.5f), 2.0f * r, 0.0f), mat));
+        }
+    // no bvh_node: the library builds its own tree over anything larger than a handful of primitives
+    shoot(world, View{kWide, 3840, 1, kSky, 40.0f, point3(0.0f, 40.0f, 130.0f), point3(0.0f, 0.0f, 0.0f), 0.0f, 10.0f});
+}
+
+int main(int argc, char **argv) {
+    if (argc < 2) {
+        fprintf(stderr, "usage: rt_scenes <scene> [--spp N] [--width W] [--depth D] [--out file.png] [--dump file.rtscene]\n");
+        return 2;
+    }
+    int synth_half = 500;
+    for (int i = 2; i + 1 < argc; i += 2) {
+        if (!strcmp(argv[i], "--spp")) g_spp = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "--width")) g_width = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "--depth")) g_depth = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "--out")) g_out = argv[i + 1];
+        else if (!strcmp(argv[i], "--dump")) setenv("RTAMD_DUMP_SCENE", argv[i + 1], 1);
+        else if (!strcmp(argv[i], "--half")) synth_half = atoi(argv[i + 1]);
+    }
+    std::string s = argv[1];
+    if (s == "bouncing_spheres") bouncing_spheres();
+    else if (s == "checkered_spheres") checkered_spheres();
+    else if (s == "earth") earth();
+    else if (s == "perlin_spheres") perlin_spheres();
+    else if (s == "quads") quads();
+    else if (s == "simple_light") simple_light();
+    else if (s == "cornell_box") cornell_box();
+    else if (s == "synth1m") synth1m(synth_half);
+    else {
+        fprintf(stderr, "unknown scene %s\n", argv[1]);
+        return 2;
+    }
+    return 0;
+}

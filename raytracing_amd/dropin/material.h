@@ -1,0 +1,3 @@
+// material.h of the reference API; everything lives in rtamd_scene_api.hpp.
+#pragma once
+#include "rtamd_scene_api.hpp"

@@ -1,0 +1,1010 @@
+// rtamd_scene_api.hpp — the reference's C++ scene-construction API as a recording front end.
+//
+// A program written against YanjieShiFennec/RayTracing (hittable_list, make_shared<sphere|quad>,
+// box, translate / rotate_y / rotate_xyz / scaling, bvh_node, the material and texture classes,
+// the public camera fields and camera::render) compiles against these headers unchanged.
+// Nothing here traces a ray: the classes only remember how they were built.  camera::render
+// (camera.h:31 in the reference) flattens the graph into an rt_scene_desc and hands it to
+// librt_amd.so through the C ABI of rt_amd.h; the image is rendered by the HIP kernels.
+//
+// Header-only and multi-TU safe (everything inline).
+#pragma once
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <limits>
+#include <map>
+#include <memory>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "rt_amd.h"
+#include "rt_scene_io.h"
+
+// rt_constants.h:11-17 puts these names at global scope; scene code relies on them
+using std::make_shared;
+using std::shared_ptr;
+using std::sqrt;
+using std::string;
+using std::fabs;
+using std::cout;
+
+const float infinity = std::numeric_limits<float>::infinity(); // rt_constants.h:20
+const float pi = 3.1415926535897932385f;                       // rt_constants.h:21
+
+inline float degrees_to_radians(float degrees) { return degrees * pi / 180.0f; }
+
+namespace rtamd {
+// The reference draws every random number, scene construction included, from one
+// default-seeded std::mt19937 through libstdc++'s uniform_real_distribution<float>
+// (rt_constants.h:28-33): one 32-bit output, converted to float, divided by 2^32, and 1.0
+// replaced by the float just below it.  Restated explicitly so that the stream does not
+// depend on the standard library this header is compiled with.
+inline std::mt19937 &generator() {
+    static std::mt19937 g; // seed 5489
+    return g;
+}
+} // namespace rtamd
+
+inline float random_float() {
+    float r = float(rtamd::generator()()) / 4294967296.0f;
+    if (r >= 1.0f) r = std::nextafter(1.0f, 0.0f);
+    return r;
+}
+inline float random_float(float min, float max) { return min + (max - min) * random_float(); }
+inline int random_int(int min, int max) { return int(random_float(float(min), float(max + 1))); }
+
+// ---------------------------------------------------------------------------------------------
+// vec3.h
+class vec3 {
+  public:
+    float e[3];
+    vec3() : e{0.0f, 0.0f, 0.0f} {}
+    vec3(float e0, float e1, float e2) : e{e0, e1, e2} {}
+    float x() const { return e[0]; }
+    float y() const { return e[1]; }
+    float z() const { return e[2]; }
+    vec3 operator-() const { return vec3(-e[0], -e[1], -e[2]); }
+    float operator[](int i) const { return e[i]; }
+    float &operator[](int i) { return e[i]; }
+    vec3 &operator+=(const vec3 &v) {
+        for (int k = 0; k < 3; k++) e[k] += v.e[k];
+        return *this;
+    }
+    vec3 &operator*=(float t) {
+        for (int k = 0; k < 3; k++) e[k] *= t;
+        return *this;
+    }
+    vec3 &operator*=(const vec3 &v) {
+        for (int k = 0; k < 3; k++) e[k] *= v.e[k];
+        return *this;
+    }
+    vec3 &operator/=(float t) { return *this *= 1.0f / t; }
+    float length_squared() const { return e[0] * e[0] + e[1] * e[1] + e[2] * e[2]; }
+    float length() const { return std::sqrt(length_squared()); }
+    bool near_zero() const {
+        const float s = 1e-8f;
+        return std::fabs(e[0]) < s && std::fabs(e[1]) < s && std::fabs(e[2]) < s;
+    }
+    // vec3.h:66-72 draws the three numbers inside one argument list; the reference's
+    // toolchain (g++) evaluates such a list right to left, so the FIRST draw becomes z.
+    // Sequenced explicitly here: the scene no longer depends on the compiler.
+    static vec3 random() {
+        float c = random_float(), b = random_float(), a = random_float();
+        return vec3(a, b, c);
+    }
+    static vec3 random(float min, float max) {
+        float c = random_float(min, max), b = random_float(min, max), a = random_float(min, max);
+        return vec3(a, b, c);
+    }
+};
+using point3 = vec3;
+using color = vec3;
+
+inline std::ostream &operator<<(std::ostream &out, const vec3 &v) { return out << v.e[0] << ' ' << v.e[1] << ' ' << v.e[2]; }
+inline vec3 operator+(const vec3 &u, const vec3 &v) { return vec3(u.e[0] + v.e[0], u.e[1] + v.e[1], u.e[2] + v.e[2]); }
+inline vec3 operator-(const vec3 &u, const vec3 &v) { return vec3(u.e[0] - v.e[0], u.e[1] - v.e[1], u.e[2] - v.e[2]); }
+inline vec3 operator*(const vec3 &u, const vec3 &v) { return vec3(u.e[0] * v.e[0], u.e[1] * v.e[1], u.e[2] * v.e[2]); }
+inline vec3 operator/(const vec3 &u, const vec3 &v) { return vec3(u.e[0] / v.e[0], u.e[1] / v.e[1], u.e[2] / v.e[2]); }
+inline vec3 operator*(float t, const vec3 &v) { return vec3(t * v.e[0], t * v.e[1], t * v.e[2]); }
+inline vec3 operator*(const vec3 &v, float t) { return t * v; }
+inline vec3 operator/(const vec3 &v, float t) { return (1.0f / t) * v; }
+inline float dot(const vec3 &u, const vec3 &v) { return u.e[0] * v.e[0] + u.e[1] * v.e[1] + u.e[2] * v.e[2]; }
+inline vec3 cross(const vec3 &u, const vec3 &v) {
+    return vec3(u.e[1] * v.e[2] - u.e[2] * v.e[1], u.e[2] * v.e[0] - u.e[0] * v.e[2], u.e[0] * v.e[1] - u.e[1] * v.e[0]);
+}
+inline vec3 unit_vector(const vec3 &v) { return v / v.length(); }
+inline vec3 random_in_unit_disk() {
+    for (;;) {
+        float b = random_float(-1.0f, 1.0f), a = random_float(-1.0f, 1.0f); // first draw -> y (see vec3::random)
+        vec3 p(a, b, 0.0f);
+        if (p.length_squared() < 1) return p;
+    }
+}
+inline vec3 random_in_unit_sphere() {
+    for (;;) {
+        vec3 p = vec3::random(-1.0f, 1.0f);
+        if (p.length_squared() < 1.0f) return p;
+    }
+}
+inline vec3 random_unit_vector() { return unit_vector(random_in_unit_sphere()); }
+inline vec3 random_on_hemisphere(const vec3 &normal) {
+    vec3 v = random_unit_vector();
+    return dot(v, normal) > 0.0f ? v : -v;
+}
+inline vec3 reflect(const vec3 &v, const vec3 &n) { return v - 2.0f * dot(v, n) * n; }
+inline vec3 refract(const vec3 &uv, const vec3 &n, float etai_over_etat) {
+    float cos_theta = std::fmin(dot(-uv, n), 1.0f);
+    vec3 perp = etai_over_etat * (uv + cos_theta * n);
+    vec3 parallel = -std::sqrt(std::fabs(1.0f - perp.length_squared())) * n;
+    return perp + parallel;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ray.h, interval.h, aabb.h, color.h (value types scene code may touch)
+class ray {
+  public:
+    ray() {}
+    ray(const point3 &origin, const vec3 &direction) : orig(origin), dir(direction), tm(0.0f) {}
+    ray(const point3 &origin, const vec3 &direction, float time) : orig(origin), dir(direction), tm(time) {}
+    const point3 &origin() const { return orig; }
+    const vec3 &direction() const { return dir; }
+    float time() const { return tm; }
+    point3 at(float t) const { return orig + t * dir; }
+
+  private:
+    point3 orig;
+    vec3 dir;
+    float tm = 0.0f;
+};
+
+class interval {
+  public:
+    float min, max;
+    interval() : min(+infinity), max(-infinity) {}
+    interval(float lo, float hi) : min(lo), max(hi) {}
+    interval(const interval &a, const interval &b) {
+        min = a.min <= b.min ? a.min : b.min;
+        max = a.max >= b.max ? a.max : b.max;
+    }
+    float size() const { return max - min; }
+    bool contains(float x) const { return min <= x && x <= max; }
+    bool surrounds(float x) const { return min < x && x < max; }
+    float clamp(float x) const { return x < min ? min : (x > max ? max : x); }
+    interval expand(float delta) const {
+        float padding = delta / 2.0f;
+        return interval(min - padding, max + padding);
+    }
+    static const interval empty, universe;
+};
+inline const interval interval::empty = interval(+infinity, -infinity);
+inline const interval interval::universe = interval(-infinity, +infinity);
+inline interval operator+(const interval &i, float d) { return interval(i.min + d, i.max + d); }
+inline interval operator+(float d, const interval &i) { return i + d; }
+inline interval operator*(const interval &i, float d) { return interval(i.min * d, i.max * d); }
+inline interval operator*(float d, const interval &i) { return i * d; }
+
+// aabb.h.  The renderer builds its own (correct, padded) bounds on the flattened primitives;
+// these boxes exist because bvh_node orders its leaves by them (bvh.h:54-73), and the order
+// decides ties, so they follow the reference's arithmetic exactly.
+class aabb {
+  public:
+    interval x, y, z;
+    aabb() {}
+    aabb(const interval &ix, const interval &iy, const interval &iz) : x(ix), y(iy), z(iz) { pad_to_minimums(); }
+    aabb(const point3 &a, const point3 &b) {
+        x = (a[0] <= b[0]) ? interval(a[0], b[0]) : interval(b[0], a[0]);
+        y = (a[1] <= b[1]) ? interval(a[1], b[1]) : interval(b[1], a[1]);
+        z = (a[2] <= b[2]) ? interval(a[2], b[2]) : interval(b[2], a[2]);
+        pad_to_minimums();
+    }
+    aabb(const aabb &b0, const aabb &b1) : x(b0.x, b1.x), y(b0.y, b1.y), z(b0.z, b1.z) {}
+    const interval &axis_interval(int n) const { return n == 1 ? y : (n == 2 ? z : x); }
+    int longest_axis() const {
+        if (x.size() > y.size()) return x.size() > z.size() ? 0 : 2;
+        return y.size() > z.size() ? 1 : 2;
+    }
+    static const aabb empty, universe;
+
+  private:
+    void pad_to_minimums() {
+        const float delta = 0.0001f;
+        if (x.size() < delta) x = x.expand(delta);
+        if (y.size() < delta) y = y.expand(delta);
+        if (z.size() < delta) z = z.expand(delta);
+    }
+};
+inline const aabb aabb::empty = aabb(interval::empty, interval::empty, interval::empty);
+inline const aabb aabb::universe = aabb(interval::universe, interval::universe, interval::universe);
+inline aabb operator+(const aabb &b, const vec3 &o) { return aabb(b.x + o.x(), b.y + o.y(), b.z + o.z()); }
+inline aabb operator+(const vec3 &o, const aabb &b) { return b + o; }
+inline aabb operator*(const aabb &b, const vec3 &s) { return aabb(b.x * s.x(), b.y * s.y(), b.z * s.z()); }
+inline aabb operator*(const vec3 &s, const aabb &b) { return b * s; }
+
+inline float linear_to_gamma(float c) { return c > 0.0f ? std::sqrt(c) : 0.0f; }
+inline void write_color(int rgb[3], const color &pixel_color) { // color.h:17-32
+    static const interval intensity(0.000f, 0.999f);
+    for (int k = 0; k < 3; k++) rgb[k] = int(256 * intensity.clamp(linear_to_gamma(pixel_color[k])));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Recorder: the flat scene under construction
+namespace rtamd {
+
+class Recorder {
+  public:
+    std::vector<rt_prim> prims;
+    std::vector<rt_group> groups;
+    std::vector<rt_material> materials;
+    std::vector<rt_texture> textures;
+    std::vector<rt_perlin> perlins;
+    std::vector<rt_image> images;
+    std::vector<uint8_t> texels;
+    std::vector<rt_xform_op> ops;
+    std::vector<rt_xform_chain> chains;
+    std::vector<rt_xform_op> open_wrappers; // outermost first
+    std::map<const void *, int> material_ids, texture_ids;
+    std::map<std::string, int> chain_ids;
+    int bvh_depth = 0; // > 0 while recording the leaves of a bvh_node
+
+    int current_chain() {
+        if (open_wrappers.empty()) return -1;
+        std::vector<rt_xform_op> inner_first(open_wrappers.rbegin(), open_wrappers.rend());
+        std::string key((const char *)inner_first.data(), inner_first.size() * sizeof(rt_xform_op));
+        auto it = chain_ids.find(key);
+        if (it != chain_ids.end()) return it->second;
+        rt_xform_chain c = {(int32_t)ops.size(), (int32_t)inner_first.size()};
+        ops.insert(ops.end(), inner_first.begin(), inner_first.end());
+        chains.push_back(c);
+        return chain_ids[key] = (int)chains.size() - 1;
+    }
+    void add_prim(rt_prim p) {
+        p.xform = current_chain();
+        int kind = bvh_depth > 0 ? RT_GROUP_BVH : RT_GROUP_LIST;
+        if (groups.empty() || groups.back().kind != kind || (kind == RT_GROUP_BVH && bvh_closed)) {
+            rt_group g = {kind, (int32_t)prims.size(), 0, 0};
+            groups.push_back(g);
+            bvh_closed = false;
+        }
+        groups.back().n_prims++;
+        prims.push_back(p);
+    }
+    void begin_bvh() {
+        if (bvh_depth++ == 0) bvh_closed = true; // the next leaf opens a fresh BVH group
+    }
+    void end_bvh() {
+        if (--bvh_depth == 0) bvh_closed = true;
+    }
+    rt_scene_desc desc() const {
+        rt_scene_desc d;
+        memset(&d, 0, sizeof(d));
+        d.abi_version = RT_AMD_ABI_VERSION;
+        d.n_prims = (int)prims.size();
+        d.prims = prims.data();
+        d.n_groups = (int)groups.size();
+        d.groups = groups.data();
+        d.n_materials = (int)materials.size();
+        d.materials = materials.data();
+        d.n_textures = (int)textures.size();
+        d.textures = textures.data();
+        d.n_perlins = (int)perlins.size();
+        d.perlins = perlins.data();
+        d.n_images = (int)images.size();
+        d.images = images.data();
+        d.n_texel_bytes = texels.size();
+        d.texels = texels.data();
+        d.n_xform_ops = (int)ops.size();
+        d.xform_ops = ops.data();
+        d.n_chains = (int)chains.size();
+        d.chains = chains.data();
+        return d;
+    }
+
+  private:
+    bool bvh_closed = true;
+};
+
+// Minimal PNG writer (8-bit RGB, stored deflate blocks): what camera::render needs to put its
+// pixels on disk (camera.h:56).  The file decodes to exactly the bytes passed in.
+inline bool write_png_rgb8(const char *path, int w, int h, const uint8_t *rgb) {
+    auto crc32 = [](const uint8_t *p, size_t n, uint32_t c) {
+        static uint32_t table[256];
+        static bool init = false;
+        if (!init) {
+            for (uint32_t i = 0; i < 256; i++) {
+                uint32_t v = i;
+                for (int k = 0; k < 8; k++) v = (v & 1) ? 0xEDB88320u ^ (v >> 1) : v >> 1;
+                table[i] = v;
+            }
+            init = true;
+        }
+        c = ~c;
+        for (size_t i = 0; i < n; i++) c = table[(c ^ p[i]) & 255] ^ (c >> 8);
+        return ~c;
+    };
+    auto be32 = [](std::vector<uint8_t> &v, uint32_t x) {
+        for (int s = 24; s >= 0; s -= 8) v.push_back((uint8_t)(x >> s));
+    };
+    std::vector<uint8_t> raw;
+    raw.reserve((size_t)h * (3 * w + 1));
+    for (int y = 0; y < h; y++) {
+        raw.push_back(0); // filter: none
+        raw.insert(raw.end(), rgb + (size_t)y * w * 3, rgb + (size_t)(y + 1) * w * 3);
+    }
+    std::vector<uint8_t> z = {0x78, 0x01};
+    uint32_t a = 1, b = 0;
+    for (uint8_t c : raw) {
+        a = (a + c) % 65521u;
+        b = (b + a) % 65521u;
+    }
+    for (size_t off = 0; off < raw.size() || off == 0; off += 65535) {
+        size_t n = std::min<size_t>(65535, raw.size() - off);
+        z.push_back(off + n >= raw.size() ? 1 : 0);
+        z.push_back((uint8_t)(n & 255));
+        z.push_back((uint8_t)(n >> 8));
+        z.push_back((uint8_t)(~n & 255));
+        z.push_back((uint8_t)((~n >> 8) & 255));
+        z.insert(z.end(), raw.begin() + off, raw.begin() + off + n);
+        if (raw.empty()) break;
+    }
+    be32(z, (b << 16) | a);
+    std::vector<uint8_t> out = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    auto chunk = [&](const char *tag, const std::vector<uint8_t> &data) {
+        be32(out, (uint32_t)data.size());
+        size_t start = out.size();
+        out.insert(out.end(), tag, tag + 4);
+        out.insert(out.end(), data.begin(), data.end());
+        be32(out, crc32(out.data() + start, out.size() - start, 0));
+    };
+    std::vector<uint8_t> ihdr;
+    be32(ihdr, (uint32_t)w);
+    be32(ihdr, (uint32_t)h);
+    ihdr.insert(ihdr.end(), {8, 2, 0, 0, 0});
+    chunk("IHDR", ihdr);
+    chunk("IDAT", z);
+    chunk("IEND", {});
+    FILE *f = fopen(path, "wb");
+    if (!f) return false;
+    bool ok = fwrite(out.data(), 1, out.size(), f) == out.size();
+    return fclose(f) == 0 && ok;
+}
+
+} // namespace rtamd
+
+// ---------------------------------------------------------------------------------------------
+// perlin.h, rtw_stb_image.h, texture.h
+class perlin {
+  public:
+    perlin() { // perlin.h:8-15: 256 unit vectors, then three permutations (two of them unused)
+        for (int i = 0; i < 256; i++) {
+            vec3 v = unit_vector(vec3::random(-1.0f, 1.0f));
+            for (int k = 0; k < 3; k++) table.randvec[i][k] = v[k];
+        }
+        int scratch[256];
+        generate_perm(table.perm_x);
+        generate_perm(scratch); // perm_y: drawn so that the random stream stays aligned
+        generate_perm(scratch); // perm_z
+    }
+    rt_perlin table;
+
+  private:
+    static void generate_perm(int32_t *p) {
+        for (int i = 0; i < 256; i++) p[i] = i;
+        for (int i = 255; i > 0; i--) {
+            int target = random_int(0, i);
+            std::swap(p[i], p[target]);
+        }
+    }
+};
+
+// Image files.  The kernels read texels in the reference's "linear byte" form: the decoded
+// 8-bit value b becomes (uchar)(256 * powf(b / 255, 2.2)) (stb's LDR->HDR conversion followed by
+// rtw_stb_image.h:96-102).  Formats understood here: binary PPM (P6), converted as above, and
+// .rtimg (a raw dump of already converted texels: "RTIMG1\n<w> <h>\n" + w*h*3 bytes).
+class rtw_image {
+  public:
+    rtw_image() {}
+    rtw_image(const char *image_filename) {
+        std::string filename(image_filename);
+        const char *imagedir = getenv("RTW_IMAGES");
+        if (imagedir && load(std::string(imagedir) + "/" + filename)) return;
+        std::string prefix;
+        if (load(filename)) return;
+        for (int up = 0; up < 7; up++) { // images/, ../images/, ... six levels up
+            if (load(prefix + "images/" + filename)) return;
+            prefix += "../";
+        }
+        std::cerr << "ERROR: Could not load image file '" << image_filename << "'.\n";
+    }
+    bool load(const std::string &name) { return load_one(name) || load_one(replace_ext(name, ".rtimg")) || load_one(replace_ext(name, ".ppm")); }
+    int width() const { return data.empty() ? 0 : w; }
+    int height() const { return data.empty() ? 0 : h; }
+    const std::vector<uint8_t> &bytes() const { return data; }
+
+  private:
+    int w = 0, h = 0;
+    std::vector<uint8_t> data;
+    static std::string replace_ext(const std::string &n, const char *ext) {
+        size_t dot = n.find_last_of('.');
+        return (dot == std::string::npos ? n : n.substr(0, dot)) + ext;
+    }
+    bool load_one(const std::string &name) {
+        FILE *f = fopen(name.c_str(), "rb");
+        if (!f) return false;
+        char magic[8] = {0};
+        int ww = 0, hh = 0, maxv = 255;
+        bool ok = false;
+        if (fscanf(f, "%7s", magic) == 1) {
+            if (!strcmp(magic, "RTIMG1") && fscanf(f, "%d %d", &ww, &hh) == 2 && fgetc(f) == '\n') {
+                data.resize((size_t)ww * hh * 3);
+                ok = ww > 0 && hh > 0 && fread(data.data(), 1, data.size(), f) == data.size();
+            } else if (!strcmp(magic, "P6") && fscanf(f, "%d %d %d", &ww, &hh, &maxv) == 3 && maxv == 255 &&
+                       isspace(fgetc(f))) {
+                data.resize((size_t)ww * hh * 3);
+                ok = ww > 0 && hh > 0 && fread(data.data(), 1, data.size(), f) == data.size();
+                for (uint8_t &b : data) {
+                    float v = powf(b / 255.0f, 2.2f);
+                    b = v <= 0.0 ? 0 : (1.0 <= v ? 255 : (uint8_t)(256.0 * v));
+                }
+            }
+        }
+        fclose(f);
+        if (!ok) data.clear();
+        w = ww;
+        h = hh;
+        return ok;
+    }
+};
+
+class texture {
+  public:
+    virtual ~texture() = default;
+    virtual int record(rtamd::Recorder &r) const = 0; // returns the texture's index
+
+  protected:
+    int memo(rtamd::Recorder &r, const rt_texture &t) const {
+        auto it = r.texture_ids.find(this);
+        if (it != r.texture_ids.end()) return it->second;
+        r.textures.push_back(t);
+        return r.texture_ids[this] = (int)r.textures.size() - 1;
+    }
+    static rt_texture blank(int type) {
+        rt_texture t;
+        memset(&t, 0, sizeof(t));
+        t.type = type;
+        t.even = t.odd = t.perlin = t.image = -1;
+        return t;
+    }
+};
+
+class solid_color : public texture {
+  public:
+    solid_color(const color &albedo) : albedo(albedo) {}
+    solid_color(float red, float green, float blue) : solid_color(color(red, green, blue)) {}
+    int record(rtamd::Recorder &r) const override {
+        rt_texture t = blank(RT_TEX_SOLID);
+        for (int k = 0; k < 3; k++) t.color[k] = albedo[k];
+        return memo(r, t);
+    }
+
+  private:
+    color albedo;
+};
+
+class checker_texture : public texture {
+  public:
+    checker_texture(float scale, shared_ptr<texture> even, shared_ptr<texture> odd)
+        : inv_scale(1.0f / scale), even(even), odd(odd) {}
+    checker_texture(float scale, const color &c1, const color &c2)
+        : checker_texture(scale, make_shared<solid_color>(c1), make_shared<solid_color>(c2)) {}
+    int record(rtamd::Recorder &r) const override {
+        auto it = r.texture_ids.find(this);
+        if (it != r.texture_ids.end()) return it->second;
+        rt_texture t = blank(RT_TEX_CHECKER);
+        t.scale = inv_scale;
+        t.even = even->record(r);
+        t.odd = odd->record(r);
+        return memo(r, t);
+    }
+
+  private:
+    float inv_scale;
+    shared_ptr<texture> even, odd;
+};
+
+class image_texture : public texture {
+  public:
+    image_texture(const char *filename) : image(filename) {}
+    int record(rtamd::Recorder &r) const override {
+        auto it = r.texture_ids.find(this);
+        if (it != r.texture_ids.end()) return it->second;
+        rt_texture t = blank(RT_TEX_IMAGE);
+        if (image.height() > 0) { // a missing file renders as (0,0,1): texture.h:62
+            rt_image im = {image.width(), image.height(), (uint64_t)r.texels.size()};
+            r.texels.insert(r.texels.end(), image.bytes().begin(), image.bytes().end());
+            t.image = (int)r.images.size();
+            r.images.push_back(im);
+        }
+        return memo(r, t);
+    }
+
+  private:
+    rtw_image image;
+};
+
+class noise_texture : public texture {
+  public:
+    noise_texture(float scale) : scale(scale) {}
+    int record(rtamd::Recorder &r) const override {
+        auto it = r.texture_ids.find(this);
+        if (it != r.texture_ids.end()) return it->second;
+        rt_texture t = blank(RT_TEX_NOISE);
+        t.scale = scale;
+        t.perlin = (int)r.perlins.size();
+        r.perlins.push_back(noise.table);
+        return memo(r, t);
+    }
+
+  private:
+    perlin noise;
+    float scale;
+};
+
+// ---------------------------------------------------------------------------------------------
+// material.h
+class material {
+  public:
+    virtual ~material() = default;
+    virtual int record(rtamd::Recorder &r) const = 0;
+
+  protected:
+    int memo(rtamd::Recorder &r, const rt_material &m) const {
+        r.materials.push_back(m);
+        return r.material_ids[this] = (int)r.materials.size() - 1;
+    }
+    bool known(rtamd::Recorder &r, int &id) const {
+        auto it = r.material_ids.find(this);
+        if (it == r.material_ids.end()) return false;
+        id = it->second;
+        return true;
+    }
+};
+
+class lambertian : public material {
+  public:
+    lambertian(const color &albedo) : tex(make_shared<solid_color>(albedo)) {}
+    lambertian(shared_ptr<texture> tex) : tex(tex) {}
+    int record(rtamd::Recorder &r) const override {
+        int id;
+        if (known(r, id)) return id;
+        rt_material m = {RT_MAT_LAMBERTIAN, tex->record(r), {0, 0, 0}, 0};
+        return memo(r, m);
+    }
+
+  private:
+    shared_ptr<texture> tex;
+};
+
+class metal : public material {
+  public:
+    metal(const color &albedo, float fuzz) : albedo(albedo), fuzz(fuzz < 1 ? fuzz : 1) {}
+    int record(rtamd::Recorder &r) const override {
+        int id;
+        if (known(r, id)) return id;
+        rt_material m = {RT_MAT_METAL, -1, {albedo[0], albedo[1], albedo[2]}, fuzz};
+        return memo(r, m);
+    }
+
+  private:
+    color albedo;
+    float fuzz;
+};
+
+class dielectric : public material {
+  public:
+    dielectric(float refraction_index) : refraction_index(refraction_index) {}
+    int record(rtamd::Recorder &r) const override {
+        int id;
+        if (known(r, id)) return id;
+        rt_material m = {RT_MAT_DIELECTRIC, -1, {0, 0, 0}, refraction_index};
+        return memo(r, m);
+    }
+
+  private:
+    float refraction_index;
+};
+
+class diffuse_light : public material {
+  public:
+    diffuse_light(shared_ptr<texture> tex) : tex(tex) {}
+    diffuse_light(const color &emit) : tex(make_shared<solid_color>(emit)) {}
+    int record(rtamd::Recorder &r) const override {
+        int id;
+        if (known(r, id)) return id;
+        rt_material m = {RT_MAT_DIFFUSE_LIGHT, tex->record(r), {0, 0, 0}, 0};
+        return memo(r, m);
+    }
+
+  private:
+    shared_ptr<texture> tex;
+};
+
+// ---------------------------------------------------------------------------------------------
+// hittable.h, hittable_list.h, sphere.h, quad.h, bvh.h
+class hit_record { // kept for source compatibility; the GPU kernels have their own record
+  public:
+    point3 p;
+    vec3 normal;
+    shared_ptr<material> mat;
+    float t = 0, u = 0, v = 0;
+    bool front_face = false;
+    void set_face_normal(const ray &r, const vec3 &outward_normal) {
+        front_face = dot(r.direction(), outward_normal) < 0;
+        normal = front_face ? outward_normal : -outward_normal;
+    }
+};
+
+class hittable {
+  public:
+    virtual ~hittable() = default;
+    virtual aabb bounding_box() const = 0;
+    // appends this object's primitives, in the order the reference would test them
+    virtual void record(rtamd::Recorder &r) const = 0;
+    virtual void print() const {}
+};
+
+class translate : public hittable {
+  public:
+    translate(shared_ptr<hittable> object, const vec3 &offset) : object(object), offset(offset) {
+        bbox = object->bounding_box() + offset;
+    }
+    aabb bounding_box() const override { return bbox; }
+    void record(rtamd::Recorder &r) const override {
+        rt_xform_op op = {RT_XF_TRANSLATE, {offset[0], offset[1], offset[2]}};
+        r.open_wrappers.push_back(op);
+        object->record(r);
+        r.open_wrappers.pop_back();
+    }
+
+  private:
+    shared_ptr<hittable> object;
+    vec3 offset;
+    aabb bbox;
+};
+
+namespace rtamd {
+// Box of a rotated object as the reference computes it (hittable.h:109-130, 227-248): it
+// takes max[c] = fmax(min[c], corner[c]), so "max" ends up as the larger of the running
+// minimum and the LAST corner.  Kept as is: only the leaf order of a bvh_node depends on it.
+template <class Rot> inline aabb rotated_box(const aabb &b, Rot rot) {
+    point3 mn(infinity, infinity, infinity), mx(-infinity, -infinity, -infinity);
+    for (int i = 0; i < 2; i++)
+        for (int j = 0; j < 2; j++)
+            for (int k = 0; k < 2; k++) {
+                float x = i * b.x.max + (1 - i) * b.x.min;
+                float y = j * b.y.max + (1 - j) * b.y.min;
+                float z = k * b.z.max + (1 - k) * b.z.min;
+                vec3 t = rot(vec3(x, y, z));
+                for (int c = 0; c < 3; c++) {
+                    mn[c] = fminf(mn[c], t[c]);
+                    mx[c] = fmaxf(mn[c], t[c]);
+                }
+            }
+    return aabb(mn, mx);
+}
+} // namespace rtamd
+
+class rotate_y : public hittable {
+  public:
+    rotate_y(shared_ptr<hittable> object, float angle) : object(object), angle(angle) {
+        float radians = degrees_to_radians(angle);
+        float s = sinf(radians), c = cosf(radians);
+        bbox = rtamd::rotated_box(object->bounding_box(),
+                                  [=](vec3 v) { return vec3(c * v.x() + s * v.z(), v.y(), -s * v.x() + c * v.z()); });
+    }
+    aabb bounding_box() const override { return bbox; }
+    void record(rtamd::Recorder &r) const override {
+        rt_xform_op op = {RT_XF_ROTATE_Y, {angle, 0.0f, 0.0f}};
+        r.open_wrappers.push_back(op);
+        object->record(r);
+        r.open_wrappers.pop_back();
+    }
+
+  private:
+    shared_ptr<hittable> object;
+    float angle;
+    aabb bbox;
+};
+
+class rotate_xyz : public hittable {
+  public:
+    rotate_xyz(shared_ptr<hittable> object, float alpha, float beta, float gamma)
+        : object(object), alpha(alpha), beta(beta), gamma(gamma) {
+        float sa = sinf(degrees_to_radians(alpha)), ca = cosf(degrees_to_radians(alpha));
+        float sb = sinf(degrees_to_radians(beta)), cb = cosf(degrees_to_radians(beta));
+        float sg = sinf(degrees_to_radians(gamma)), cg = cosf(degrees_to_radians(gamma));
+        bbox = rtamd::rotated_box(object->bounding_box(), [=](vec3 v) { // hittable.h:284-295
+            float vx = cb * cg * v.x() + (sa * sb * cg - sg * ca) * v.y() + (sb * ca * cg + sa * sg) * v.z();
+            float vy = cb * sg * v.x() + (ca * cg + sa * sb * sg) * v.y() + (-sa * cg + sg * sb * ca) * v.z();
+            float vz = -sb * v.x() + sa * cb * v.y() + ca * cb * v.z();
+            return vec3(vx, vy, vz);
+        });
+    }
+    aabb bounding_box() const override { return bbox; }
+    void record(rtamd::Recorder &r) const override {
+        rt_xform_op op = {RT_XF_ROTATE_XYZ, {alpha, beta, gamma}};
+        r.open_wrappers.push_back(op);
+        object->record(r);
+        r.open_wrappers.pop_back();
+    }
+
+  private:
+    shared_ptr<hittable> object;
+    float alpha, beta, gamma;
+    aabb bbox;
+};
+
+class scaling : public hittable {
+  public:
+    scaling(shared_ptr<hittable> object, const vec3 &scale) : object(object), scale(scale) {
+        bbox = object->bounding_box() * scale;
+    }
+    aabb bounding_box() const override { return bbox; }
+    void record(rtamd::Recorder &r) const override {
+        rt_xform_op op = {RT_XF_SCALE, {scale[0], scale[1], scale[2]}};
+        r.open_wrappers.push_back(op);
+        object->record(r);
+        r.open_wrappers.pop_back();
+    }
+
+  private:
+    shared_ptr<hittable> object;
+    vec3 scale;
+    aabb bbox;
+};
+
+class hittable_list : public hittable {
+  public:
+    std::vector<shared_ptr<hittable>> objects;
+    hittable_list() {}
+    hittable_list(shared_ptr<hittable> object) { add(object); }
+    void clear() { objects.clear(); }
+    void add(shared_ptr<hittable> object) {
+        objects.push_back(object);
+        bbox = aabb(bbox, object->bounding_box());
+    }
+    aabb bounding_box() const override { return bbox; }
+    void record(rtamd::Recorder &r) const override {
+        for (const auto &o : objects) o->record(r);
+    }
+    void print() const override {
+        for (const auto &o : objects) o->print();
+    }
+
+  private:
+    aabb bbox;
+};
+
+class sphere : public hittable {
+  public:
+    sphere(const point3 &center, float radius, shared_ptr<material> mat)
+        : center1(center), center2(center), radius(std::fmax(0.0f, radius)), mat(mat), is_moving(false) {
+        vec3 rvec(radius, radius, radius);
+        bbox = aabb(center1 - rvec, center1 + rvec);
+    }
+    sphere(const point3 &c1, const point3 &c2, float radius, shared_ptr<material> mat)
+        : center1(c1), center2(c2), radius(std::fmax(0.0f, radius)), mat(mat), is_moving(true) {
+        vec3 rvec(radius, radius, radius);
+        bbox = aabb(aabb(c1 - rvec, c1 + rvec), aabb(c2 - rvec, c2 + rvec));
+        center_vec = c2 - c1;
+    }
+    aabb bounding_box() const override { return bbox; }
+    void record(rtamd::Recorder &r) const override {
+        rt_prim p;
+        memset(&p, 0, sizeof(p));
+        p.type = RT_PRIM_SPHERE;
+        p.material = mat->record(r);
+        p.flags = is_moving ? RT_PRIM_FLAG_MOVING : 0;
+        for (int k = 0; k < 3; k++) {
+            p.a[k] = center1[k];
+            p.b[k] = is_moving ? center_vec[k] : 0.0f;
+            p.d[k] = is_moving ? center2[k] : 0.0f;
+        }
+        p.c[0] = radius;
+        r.add_prim(p);
+    }
+    void print() const override { std::cout << bbox.x.min << " " << bbox.y.min << " " << bbox.z.min << std::endl; }
+
+  private:
+    point3 center1, center2;
+    float radius;
+    shared_ptr<material> mat;
+    bool is_moving;
+    vec3 center_vec;
+    aabb bbox;
+};
+
+class quad : public hittable {
+  public:
+    quad(const point3 &Q, const point3 &u, const point3 &v, shared_ptr<material> mat) : Q(Q), u(u), v(v), mat(mat) {
+        bbox = aabb(aabb(Q, Q + u + v), aabb(Q + u, Q + v)); // quad.h:25-30
+    }
+    aabb bounding_box() const override { return bbox; }
+    void record(rtamd::Recorder &r) const override {
+        rt_prim p;
+        memset(&p, 0, sizeof(p));
+        p.type = RT_PRIM_QUAD;
+        p.material = mat->record(r);
+        for (int k = 0; k < 3; k++) {
+            p.a[k] = Q[k];
+            p.b[k] = u[k];
+            p.c[k] = v[k];
+        }
+        r.add_prim(p);
+    }
+    void print() const override { std::cout << bbox.x.min << " " << bbox.y.min << " " << bbox.z.min << std::endl; }
+
+  private:
+    point3 Q;
+    vec3 u, v;
+    shared_ptr<material> mat;
+    aabb bbox;
+};
+
+inline shared_ptr<hittable_list> box(const point3 &a, const point3 &b, shared_ptr<material> mat) { // quad.h:111-131
+    auto sides = make_shared<hittable_list>();
+    point3 lo(std::fmin(a.x(), b.x()), std::fmin(a.y(), b.y()), std::fmin(a.z(), b.z()));
+    point3 hi(std::fmax(a.x(), b.x()), std::fmax(a.y(), b.y()), std::fmax(a.z(), b.z()));
+    vec3 dx(hi.x() - lo.x(), 0.0f, 0.0f), dy(0.0f, hi.y() - lo.y(), 0.0f), dz(0.0f, 0.0f, hi.z() - lo.z());
+    const struct {
+        point3 corner;
+        vec3 e0, e1;
+    } faces[6] = {{point3(lo.x(), lo.y(), hi.z()), dx, dy},  {point3(hi.x(), lo.y(), hi.z()), -dz, dy},
+                  {point3(hi.x(), lo.y(), lo.z()), -dx, dy}, {point3(lo.x(), lo.y(), lo.z()), dz, dy},
+                  {point3(lo.x(), hi.y(), hi.z()), dx, -dz}, {point3(lo.x(), lo.y(), lo.z()), dx, dz}};
+    for (const auto &f : faces) sides->add(make_shared<quad>(f.corner, f.e0, f.e1, mat));
+    return sides;
+}
+
+// bvh.h.  The renderer builds its own tree over the flattened primitives; this class only
+// reproduces the ORDER in which the reference's tree would test its leaves (the recursive
+// std::sort by box minimum along the longest axis, bvh.h:48-75), because that order decides
+// which of two coincident primitives wins.
+class bvh_node : public hittable {
+  public:
+    bvh_node(hittable_list list) : bvh_node(list.objects, 0, list.objects.size()) {}
+    bvh_node(std::vector<shared_ptr<hittable>> &objects, size_t start, size_t end) {
+        order(objects, start, end);
+        leaves.assign(objects.begin() + start, objects.begin() + end);
+        bbox = aabb::empty;
+        for (const auto &o : leaves) bbox = aabb(bbox, o->bounding_box());
+    }
+    aabb bounding_box() const override { return bbox; }
+    void record(rtamd::Recorder &r) const override {
+        r.begin_bvh();
+        for (const auto &o : leaves) o->record(r);
+        r.end_bvh();
+    }
+    void print() const override {
+        for (const auto &o : leaves) o->print();
+    }
+
+  private:
+    std::vector<shared_ptr<hittable>> leaves;
+    aabb bbox;
+    static void order(std::vector<shared_ptr<hittable>> &objects, size_t start, size_t end) {
+        size_t span = end - start;
+        if (span <= 2) return;
+        aabb bb = aabb::empty;
+        for (size_t i = start; i < end; i++) bb = aabb(bb, objects[i]->bounding_box());
+        int axis = bb.longest_axis();
+        std::sort(objects.begin() + start, objects.begin() + end,
+                  [axis](const shared_ptr<hittable> a, const shared_ptr<hittable> b) {
+                      return a->bounding_box().axis_interval(axis).min < b->bounding_box().axis_interval(axis).min;
+                  });
+        size_t mid = start + span / 2;
+        order(objects, start, mid);
+        order(objects, mid, end);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// camera.h
+class camera {
+  public:
+    float aspect_ratio = 1.0f;
+    int image_width = 100;
+    int samples_per_pixel = 10;
+    int max_depth = 10;
+    color background;
+    float vfov = 90.0f;
+    point3 lookfrom = point3(0.0f, 0.0f, 0.0f);
+    point3 lookat = point3(0.0f, 0.0f, -1.0f);
+    vec3 vup = vec3(0.0f, 1.0f, 0.0f);
+    float defocus_angle = 0.0f;
+    float focus_dist = 10.0f;
+
+    // Extensions (not in the reference): which GPU renders, and the sampler seed.
+    int device = 0;
+    uint32_t seed = 0;
+
+    rt_camera_desc descriptor() const {
+        rt_camera_desc c;
+        memset(&c, 0, sizeof(c));
+        c.aspect_ratio = aspect_ratio;
+        c.image_width = image_width;
+        c.samples_per_pixel = samples_per_pixel;
+        c.max_depth = max_depth;
+        c.vfov = vfov;
+        c.defocus_angle = defocus_angle;
+        c.focus_dist = focus_dist;
+        for (int k = 0; k < 3; k++) {
+            c.background[k] = background[k];
+            c.lookfrom[k] = lookfrom[k];
+            c.lookat[k] = lookat[k];
+            c.vup[k] = vup[k];
+        }
+        return c;
+    }
+
+    // Replaces camera::render (camera.h:31-63): same arguments, same outputs (a PNG at
+    // file_name, progress on clog, "Render took ... seconds." on cerr).  The sample loop runs
+    // on the GPU.  Like the reference it reports no errors to the caller; a failure of the
+    // library is printed and the process exits, since no image can be produced.
+    void render(const hittable &world, const char *file_name) {
+        auto t0 = std::chrono::steady_clock::now();
+        rtamd::Recorder rec;
+        world.record(rec);
+        rt_scene_desc sd = rec.desc();
+        rt_camera_desc cd = descriptor();
+        const char *dump = getenv("RTAMD_DUMP_SCENE"); // fixture generation: write the flat scene and stop
+        if (dump) {
+            if (rt_scene_file_save(&sd, dump) != RT_OK) die("rt_scene_file_save");
+            std::string camfile = std::string(dump) + ".cam";
+            rt_camera_frame fr;
+            if (rt_camera_initialize(&cd, &fr) != RT_OK) die("rt_camera_initialize");
+            FILE *f = fopen(camfile.c_str(), "wb");
+            if (!f || fwrite(&cd, sizeof(cd), 1, f) != 1 || fwrite(&fr, sizeof(fr), 1, f) != 1) die("camera dump");
+            fclose(f);
+            return;
+        }
+        rt_camera_frame frame;
+        if (rt_camera_initialize(&cd, &frame) != RT_OK) die("rt_camera_initialize");
+        rt_scene *scene = nullptr;
+        if (rt_scene_create(&sd, device, 0, &scene) != RT_OK) die("rt_scene_create");
+        const int W = frame.image_width, H = frame.image_height;
+        std::vector<float> accum((size_t)W * H * 3, 0.0f);
+        rt_render_opts opts;
+        memset(&opts, 0, sizeof(opts));
+        opts.sample_begin = 0;
+        opts.sample_count = samples_per_pixel;
+        opts.seed = seed;
+        opts.mode = RT_MODE_MEGAKERNEL;
+        std::clog << "\rScan lines remaining: " << H << ' ' << std::flush;
+        rt_render_stats stats;
+        if (rt_render(scene, &cd, &opts, accum.data(), &stats) != RT_OK) die("rt_render");
+        std::vector<uint8_t> rgb((size_t)W * H * 3);
+        if (rt_tonemap_u8(accum.data(), (int64_t)W * H, frame.pixel_samples_scale, rgb.data()) != RT_OK) die("rt_tonemap_u8");
+        rt_scene_destroy(scene);
+        if (!rtamd::write_png_rgb8(file_name, W, H, rgb.data()))
+            std::cerr << "ERROR: could not write '" << file_name << "'.\n";
+        std::clog << "\rDone.\n";
+        double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::cerr << "Render took " << seconds << " seconds.\n";
+        last_stats = stats;
+    }
+    rt_render_stats last_stats = {};
+
+  private:
+    [[noreturn]] static void die(const char *what) {
+        std::cerr << "rtamd: " << what << " failed: " << rt_last_error() << "\n";
+        exit(1);
+    }
+};
