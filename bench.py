@@ -87,7 +87,7 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from raytracing_amd import abi, binding
+    from raytracing_amd import abi, binding, spp_split
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -111,12 +111,11 @@ def main():
     accum = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
+    render_fn = spp_split.gpu_render_fn(scene, cam, seed=0)
+
     def step():
-        accum.zero_()
-        scene.render_device(cam, args.spp, accum.data_ptr(), stream=stream, sample_begin=rank * args.spp,
-                            seed=0)
-        if world > 1:
-            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+        # rank r renders global samples [r*spp, (r+1)*spp); one RCCL sum-reduce to rank 0
+        spp_split.render_split(render_fn, accum, args.spp * world)
 
     # one instrumented, untimed pass: rays and test counts of exactly the work a step does
     st = scene.render_device(cam, args.spp, accum.data_ptr(), stream=stream, sample_begin=rank * args.spp,
