@@ -43,6 +43,26 @@ def algorithmic_flops(st):
     return float(f)
 
 
+def measured_traffic(scene, width, height, spp):
+    """HBM bytes per launch of the render kernel from the PMC passes committed under profiles/
+    (FETCH_SIZE / WRITE_SIZE cannot be read from inside this process); None if no profile
+    matches the workload."""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if not name.endswith("hbm_traffic.json"):
+            continue
+        try:
+            with open(os.path.join(pdir, name)) as f:
+                t = json.load(f)
+            w = t["workload"]
+            if (w["scene"], w["width"], w["height"], w["spp_per_launch"]) == (scene, width, height, spp):
+                best = float(t["traffic_bytes_per_launch"])
+        except (OSError, KeyError, ValueError):
+            continue
+    return best
+
+
 def cpu_baseline(scene, budget_paths):
     """Times the reference renderer (oracle/_ref/rt_ref, built from the unmodified reference in
     the authoring container) on one host core; falls back to the oracle port if it is absent."""
@@ -175,7 +195,8 @@ def main():
                        "max_depth": cam.max_depth, "parallelism": f"spp-split x{world} + RCCL reduce"
                        if world > 1 else "single GPU", "mode": "megakernel"},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS,
+                         "traffic": measured_traffic(args.scene, W, H, args.spp), "traffic_unit": "bytes/launch",
                          "kernel": "render_mega", "kernel_ms_avg": avg_kernel_s * 1e3,
                          "launches": n_launches, "algorithmic_flops_per_launch": alg_flops / launches_per_step,
                          "counts_per_launch": {"paths": st.paths, "rays": st.rays, "box_tests": st.box_tests,
