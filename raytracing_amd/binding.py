@@ -10,7 +10,9 @@ import numpy as np
 
 from . import abi
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "librt_amd.so")
+# RT_AMD_LIB: load another build of the same library (tuning experiments)
+LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib",
+                                                       "librt_amd.so")
 
 # every symbol include/rt_amd.h declares
 EXPORTS = ["rt_last_error", "rt_abi_version", "rt_device_count", "rt_camera_initialize",

@@ -108,6 +108,7 @@ struct DevScene {
     int traversal; // TRAV_*
     int n_chains;
     int n_xf_ops;
+    int lds_records; // LDS staging also covers rec_i / rec_f / textures (else only slots + nodes)
 };
 
 // The five hot arrays, wherever they currently live (HBM or this workgroup's LDS).
@@ -383,7 +384,7 @@ RT_HD bool tie_prefers_candidate(int cand_id, bool cand_is_quad, int best_id, bo
 struct BoxRay { // per-ray constants of the slab test
     f3 inv;  // ~1/d (a zero component is replaced by a huge finite reciprocal)
     f3 oi;   // -(o * inv)
-    float e; // absolute slack: covers the rounding of o*inv inside fma(plane, inv, -o*inv)
+    float e2; // absolute slack: covers the rounding of o*inv inside fma(plane, inv, -o*inv)
 };
 RT_HD float safe_rcp(float d) {
     // |d| below 1e-30 would overflow; a slab that the ray runs (almost) parallel to
@@ -409,7 +410,7 @@ RT_HD BoxRay make_box_ray(const Ray &r) {
     float mx = fabsf(r.d.x) < 1e-30f ? 0.0f : fabsf(oi.x);
     float my = fabsf(r.d.y) < 1e-30f ? 0.0f : fabsf(oi.y);
     float mz = fabsf(r.d.z) < 1e-30f ? 0.0f : fabsf(oi.z);
-    b.e = 4.76837158e-7f * fmaxf(mx, fmaxf(my, mz));
+    b.e2 = 9.5367431640625e-7f * fmaxf(mx, fmaxf(my, mz));
     return b;
 }
 // Conservative ray/box overlap on [tmin, tmax]: returns the (slightly early) entry
@@ -420,9 +421,10 @@ RT_HD float box_entry(f3 lo, f3 hi, const BoxRay &b, float tmin, float tmax) {
     float az = __builtin_fmaf(lo.z, b.inv.z, b.oi.z), bz = __builtin_fmaf(hi.z, b.inv.z, b.oi.z);
     float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
     float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
-    // absolute slack e plus a relative one for the rounding of the fma results themselves
-    float slack = __builtin_fmaf(9.5367431640625e-7f, fmaxf(fabsf(tn), fabsf(tf)), b.e + b.e);
-    return (tn <= tf + slack) ? tn : RT_INF;
+    // exit parameter widened by the absolute slack (2e) and a relative one (2^-19 |tf|) for the
+    // rounding of the fma results themselves; when the test is close, |tn| ~ |tf|
+    float tf_wide = __builtin_fmaf(1.9073486328125e-6f, fabsf(tf), tf + b.e2);
+    return (tn <= tf_wide) ? tn : RT_INF;
 }
 
 #ifndef RT_STACK_DEPTH
@@ -469,16 +471,19 @@ RT_HD void trav_inner(Trav &tv, const f4 *nodes, float tmin, StackT *stack, int 
     float e1 = box_entry(mk(n1.z, n1.w, n2.x), mk(n2.y, n2.z, n2.w), tv.br, tmin, tv.best_t);
     int r0 = __builtin_bit_cast(int, n3.x), r1 = __builtin_bit_cast(int, n3.y);
     bool h0 = e0 < RT_INF, h1 = e1 < RT_INF;
+    // selects instead of a three-way branch: the nearer hit child is visited next, the other
+    // hit child (if any) is pushed; only "no child hit" needs the stack read
+    bool second_first = h1 && (!h0 || e1 < e0);
+    int nearr = second_first ? r1 : r0;
+    int farr = second_first ? r0 : r1;
     if (h0 && h1) {
-        bool swap = e1 < e0;
-        stack[tv.sp] = (StackT)(swap ? r0 : r1);
+        stack[tv.sp] = (StackT)farr;
         tv.sp += stack_stride;
-        tv.ref = swap ? r1 : r0;
-    } else if (h0 || h1) {
-        tv.ref = h0 ? r0 : r1;
-    } else {
-        trav_pop(tv, stack, stack_stride);
     }
+    if (h0 || h1)
+        tv.ref = nearr;
+    else
+        trav_pop(tv, stack, stack_stride);
 }
 // Exact test of one leaf against the current best (ties included).
 template <bool COUNT>

@@ -62,6 +62,7 @@ struct rt_scene {
     unsigned long long *d_words = nullptr; // [0] pool counter, [1] ray counter
     rtc::Counters *d_counters = nullptr;
     int n_cu = 256;
+    LaunchGeom geom; // persistent render kernel: grid, block, LDS bytes, what is staged
     // optional per-launch timing of the render kernel
     bool profiling = false;
     std::vector<hipEvent_t> prof_events; // pairs
@@ -135,6 +136,54 @@ size_t scene_lds_bytes(const rtc::DevScene &dv) {
     size_t words = (size_t)dv.n_slots * dv.slot_f4 + (size_t)dv.n_nodes * 4 + (size_t)dv.n_slots * 2;
     size_t tex = ((size_t)dv.n_textures * sizeof(rt_texture) + 15) / 16;
     return (words + tex) * sizeof(f4);
+}
+
+int env_int(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+// Workgroup shape of the persistent render kernel and what it stages into LDS.  The
+// kernels are compiled for mega_waves_per_simd() waves per SIMD; a CU is filled with
+// that many waves if the per-workgroup LDS (scene copy + traversal stacks) allows it.
+LaunchGeom choose_geom(rt_scene *s, uint32_t flags) {
+    LaunchGeom lg;
+    rtc::DevScene &dv = s->dev;
+    const bool bvh = dv.traversal == rtc::TRAV_BVH;
+    const int levels = s->info.bvh_depth + 1;
+    const size_t geom_bytes = ((size_t)dv.n_slots * dv.slot_f4 + (size_t)dv.n_nodes * 4) * sizeof(f4);
+    const size_t all_bytes = scene_lds_bytes(dv);
+    const int block = std::max(64, std::min(1024, env_int("RT_AMD_BLOCK", 1024) / 64 * 64));
+    const int threads_per_cu = rtl::mega_waves_per_simd() * 256;
+    const int bpc_target = std::max(1, env_int("RT_AMD_BLOCKS_PER_CU", threads_per_cu / block));
+    const bool short_ok = dv.n_nodes < 32768 && dv.n_slots < 16384; // 16-bit stack entries
+    lg.block = block;
+    lg.lds_scene = false;
+    dv.lds_records = 0;
+    int bpc = bpc_target;
+    if (!(flags & RT_SCENE_FORCE_GLOBAL) && short_ok) {
+        for (bpc = bpc_target; bpc >= 1 && !lg.lds_scene; bpc--) {
+            size_t budget = (size_t)kMaxLdsBytes / bpc;
+            size_t stack = bvh ? (size_t)levels * block * sizeof(short) : 0;
+            if (all_bytes + stack <= budget) {
+                lg.lds_scene = true;
+                dv.lds_records = 1;
+                lg.lds_bytes = (int)(all_bytes + stack);
+            } else if (geom_bytes + stack <= budget) {
+                lg.lds_scene = true;
+                lg.lds_bytes = (int)(geom_bytes + stack);
+            }
+            if (lg.lds_scene) break;
+        }
+    }
+    if (!lg.lds_scene) { // geometry stays in HBM; only the 32-bit stacks use LDS
+        size_t stack = bvh ? (size_t)levels * block * sizeof(int) : 0;
+        bpc = std::max(1, std::min(bpc_target, (int)(kMaxLdsBytes / std::max<size_t>(stack, 1))));
+        lg.lds_bytes = (int)stack;
+    }
+    lg.lds_bytes = std::max(lg.lds_bytes, 16);
+    lg.grid = s->n_cu * std::max(bpc, 1);
+    return lg;
 }
 
 int set_device(int device) {
@@ -257,14 +306,8 @@ int rt_scene_create(const rt_scene_desc *d, int device, uint32_t flags, rt_scene
         return fail(RT_ERR_HIP, "cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
     }
 
-    // Does the geometry fit LDS next to the traversal stacks?
-    size_t scene_bytes = scene_lds_bytes(dv);
-    bool short_ok = dv.n_nodes < 32768 && n < 16384;
-    s->info.lds_resident = 0;
-    if (!(flags & RT_SCENE_FORCE_GLOBAL) && short_ok) {
-        size_t stack = linear ? 0 : (size_t)(s->info.bvh_depth + 1) * 256 * sizeof(short);
-        if (scene_bytes + stack <= (size_t)kMaxLdsBytes) s->info.lds_resident = 1;
-    }
+    s->geom = choose_geom(s, flags);
+    s->info.lds_resident = s->geom.lds_scene ? 1 : 0;
     *out = s;
     return RT_OK;
 }
@@ -278,40 +321,6 @@ int rt_scene_get_info(const rt_scene *s, rt_scene_info *out) {
 } // extern "C"
 
 namespace {
-
-// Workgroup shape of the persistent render kernel for this scene.
-LaunchGeom choose_geom(const rt_scene *s) {
-    LaunchGeom lg;
-    const rtc::DevScene &dv = s->dev;
-    const bool bvh = dv.traversal == rtc::TRAV_BVH;
-    const int levels = s->info.bvh_depth + 1;
-    size_t scene_bytes = scene_lds_bytes(dv);
-    lg.lds_scene = s->info.lds_resident != 0;
-    int block = 1024;
-    const char *env_block = getenv("RT_AMD_BLOCK");
-    if (env_block) block = std::max(64, std::min(1024, atoi(env_block) / 64 * 64));
-    for (;; block /= 2) {
-        size_t stack = bvh ? (size_t)levels * block * (lg.lds_scene ? sizeof(short) : sizeof(int)) : 0;
-        size_t total = (lg.lds_scene ? scene_bytes : 0) + stack;
-        if (total <= (size_t)kMaxLdsBytes || block <= 64) {
-            lg.block = block;
-            lg.lds_bytes = (int)std::max<size_t>(total, 16);
-            break;
-        }
-    }
-    int per_cu_lds = kMaxLdsBytes / std::max(lg.lds_bytes, 1);
-    int per_cu_waves = 1024 / lg.block; // 16 waves per CU: the kernels use up to 128 VGPRs
-    int per_cu = std::max(1, std::min(per_cu_lds, per_cu_waves));
-    const char *env_mult = getenv("RT_AMD_BLOCKS_PER_CU");
-    if (env_mult) per_cu = std::max(1, atoi(env_mult));
-    lg.grid = s->n_cu * per_cu;
-    return lg;
-}
-
-int env_int(const char *name, int dflt) {
-    const char *e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
 
 size_t stage_budget_bytes() {
     const char *e = getenv("RT_AMD_STAGE_MB");
@@ -363,7 +372,7 @@ int rt_render_device(rt_scene *s, const rt_camera_desc *cam, const rt_render_opt
     }
 
     const bool count = (opts->flags & RT_RENDER_COUNTERS) != 0 && stats != nullptr;
-    LaunchGeom lg = choose_geom(s);
+    const LaunchGeom lg = s->geom;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (stats) {
         RT_HIP(hipEventCreate(&ev0));
@@ -386,9 +395,11 @@ int rt_render_device(rt_scene *s, const rt_camera_desc *cam, const rt_render_opt
         rp.stage = s->stage;
         rp.next_chunk = reinterpret_cast<unsigned *>(s->d_words);
         rp.counters = count ? s->d_counters : nullptr;
-        rp.scheduler = env_int("RT_AMD_SCHEDULER", 0);
-        rp.min_ready = std::max(1, std::min(64, env_int("RT_AMD_MIN_READY", 24)));
-        rp.leaf_min = std::max(1, std::min(64, env_int("RT_AMD_LEAF_MIN", 1)));
+        rp.scheduler = env_int("RT_AMD_SCHEDULER", 1);
+        rp.min_ready = std::max(1, std::min(64, env_int("RT_AMD_MIN_READY", 40)));
+        rp.leaf_min = std::max(1, std::min(64, env_int("RT_AMD_LEAF_MIN", 24)));
+        rp.blocked_min = std::max(1, std::min(64, env_int("RT_AMD_BLOCKED_MIN", 8)));
+        rp.regen_min = std::max(1, std::min(64, env_int("RT_AMD_REGEN_MIN", 1)));
         RT_HIP(hipMemsetAsync(s->d_words, 0, sizeof(unsigned long long), stream));
         hipEvent_t p0 = nullptr, p1 = nullptr;
         if (s->profiling) {

@@ -22,6 +22,10 @@
 
 using namespace rtc;
 
+#ifndef RT_INNER_UNROLL
+#define RT_INNER_UNROLL 4
+#endif
+
 namespace {
 
 __device__ __forceinline__ unsigned wave_bcast32(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -60,16 +64,18 @@ __device__ __forceinline__ f4 *stage_scene(const DevScene &sc, f4 *smem, SceneVi
     stage_to_lds(p, sc.nodes, n_node_words);
     v.nodes = p;
     p += n_node_words;
-    stage_to_lds(p, reinterpret_cast<const f4 *>(sc.rec_i), sc.n_slots);
-    v.rec_i = reinterpret_cast<const i4 *>(p);
-    p += sc.n_slots;
-    stage_to_lds(p, sc.rec_f, sc.n_slots);
-    v.rec_f = p;
-    p += sc.n_slots;
-    // the device copy of the texture table is padded to whole 16-byte words
-    stage_to_lds(p, reinterpret_cast<const f4 *>(sc.textures), n_tex_words);
-    v.textures = reinterpret_cast<const rt_texture *>(p);
-    p += n_tex_words;
+    if (sc.lds_records) {
+        stage_to_lds(p, reinterpret_cast<const f4 *>(sc.rec_i), sc.n_slots);
+        v.rec_i = reinterpret_cast<const i4 *>(p);
+        p += sc.n_slots;
+        stage_to_lds(p, sc.rec_f, sc.n_slots);
+        v.rec_f = p;
+        p += sc.n_slots;
+        // the device copy of the texture table is padded to whole 16-byte words
+        stage_to_lds(p, reinterpret_cast<const f4 *>(sc.textures), n_tex_words);
+        v.textures = reinterpret_cast<const rt_texture *>(p);
+        p += n_tex_words;
+    }
     __syncthreads();
     return p;
 }
@@ -141,7 +147,7 @@ __device__ __forceinline__ void write_record(const RenderParams &rp, unsigned s_
 // One whole ray per lane per iteration.  Linear scenes: every lane walks the same
 // primitive list, so the traversal itself is divergence-free.
 template <int TRAV, bool LDS_SCENE, bool COUNT>
-__global__ void __launch_bounds__(RT_MEGA_MAX_THREADS)
+__global__ void __launch_bounds__(RT_MEGA_MAX_THREADS, RT_MEGA_WAVES_PER_SIMD)
 render_mega(DevScene sc, DevCamera cam, RenderParams rp) {
     extern __shared__ f4 smem[];
     SceneView vw = global_view(sc);
@@ -159,6 +165,9 @@ render_mega(DevScene sc, DevCamera cam, RenderParams rp) {
     PathState ps;
     unsigned pixel = 0, sample = 0, n_rays = 0;
     Cnt<COUNT> cn;
+    // instrumented variant: per-wave cycle split {whole loop, trace, shade, iterations, live lanes}
+    unsigned long long w_cycles[5] = {0, 0, 0, 0, 0};
+    long long t_iter = COUNT ? clock64() : 0;
 
     for (;;) {
         unsigned long long need = __ballot(!alive);
@@ -186,20 +195,61 @@ render_mega(DevScene sc, DevCamera cam, RenderParams rp) {
             continue;
         }
         if (alive) {
-            bool cont = path_step<TRAV, COUNT, StackT>(sc, vw, cam, ps, stack, stack_stride, n_rays, cn);
+            bool cont;
+            if constexpr (COUNT) {
+                // instrumented variant: split the segment to time trace and shade separately
+                long long c0 = clock64();
+                cont = false;
+                TraceHit h;
+                h.slot = -1;
+                h.t = 0.0f;
+                bool go = ps.depth > 0;
+                if (go) {
+                    n_rays++;
+                    if constexpr (TRAV == TRAV_LINEAR)
+                        h = trace_linear<COUNT>(sc, vw, ps.ray, 0.001f, RT_INF, cn);
+                    else
+                        h = trace_bvh<COUNT, StackT>(sc, vw, ps.ray, 0.001f, RT_INF, stack, stack_stride, cn);
+                }
+                long long c1 = clock64();
+                if (go) cont = path_after_trace<COUNT>(sc, vw, cam, ps, h, cn);
+                long long c2 = clock64();
+                if (lane == __builtin_ctzll(__ballot(true))) {
+                    w_cycles[1] += c1 - c0;
+                    w_cycles[2] += c2 - c1;
+                    w_cycles[3] += 1;
+                    w_cycles[4] += __popcll(__ballot(true));
+                }
+            } else {
+                cont = path_step<TRAV, COUNT, StackT>(sc, vw, cam, ps, stack, stack_stride, n_rays, cn);
+            }
             if (!cont) {
                 write_record(rp, sample, pixel, ps.L, n_rays);
                 alive = false;
             }
         }
+        if constexpr (COUNT) {
+            long long now = clock64();
+            if (lane == 0) {
+                w_cycles[0] += now - t_iter;
+                t_iter = now;
+            }
+        }
     }
-    if constexpr (COUNT) flush_counters<COUNT>(rp.counters, cn);
+    if constexpr (COUNT) {
+        flush_counters<COUNT>(rp.counters, cn);
+        for (int k = 0; k < 5; k++) {
+            unsigned long long v = w_cycles[k];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if (lane == 0) atomicAdd(&rp.counters->sched[k], v);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
 // BVH scenes: traversal and shading are decoupled (see the header comment).
 template <bool LDS_SCENE, bool COUNT>
-__global__ void __launch_bounds__(RT_MEGA_MAX_THREADS)
+__global__ void __launch_bounds__(RT_MEGA_MAX_THREADS, RT_MEGA_WAVES_PER_SIMD)
 render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
     extern __shared__ f4 smem[];
     SceneView vw = global_view(sc);
@@ -213,6 +263,9 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
     const unsigned long long lane_mask_lt = (1ull << lane) - 1ull;
     const int min_ready = rp.min_ready;
     const int leaf_min = rp.leaf_min;
+    const int blocked_min = rp.blocked_min;
+    const int regen_min = rp.regen_min;
+    int pend = 0; // parked leaf reference (leaf references are negative; 0 = none)
 
     enum { ST_IDLE = 0, ST_TRAV = 1, ST_READY = 2 };
     WavePool wp;
@@ -250,7 +303,9 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
         }
         // ---- hand new paths to idle lanes -------------------------------------------------------
         unsigned long long need = __ballot(state == ST_IDLE);
-        if (need != 0ull) {
+        // starting paths (camera ray, sampler seed) is batched like everything else: wait
+        // until regen_min lanes are idle unless nothing else is left to do
+        if (need != 0ull && (__popcll(need) >= regen_min || !__any(state == ST_TRAV))) {
             pool_refill(wp, rp, lane);
             if (wp.k < wp.k_end) {
                 unsigned n_need = (unsigned)__popcll(need);
@@ -292,24 +347,41 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
                     w_t_lanes += __popcll(im0);
                 }
             }
-            if (state == ST_TRAV && tv.ref >= 0)
-                trav_inner<COUNT, StackT>(tv, vw.nodes, 0.001f, stack, stack_stride, cn);
-            bool at_leaf = state == ST_TRAV && tv.ref < 0 && tv.ref != RT_TRAV_DONE;
-            unsigned long long lmask = __ballot(at_leaf);
-            if (lmask != 0ull) {
-                unsigned long long imask = __ballot(state == ST_TRAV && tv.ref >= 0);
-                if (__popcll(lmask) >= leaf_min || imask == 0ull) {
+            const bool trav = state == ST_TRAV;
+            // RT_INNER_UNROLL node steps per scheduling decision: the ballots / thresholds
+            // below cost about as much as a node step, so they are amortised.
+#pragma unroll
+            for (int k = 0; k < RT_INNER_UNROLL; k++) {
+                if (trav && tv.ref >= 0) trav_inner<COUNT, StackT>(tv, vw.nodes, 0.001f, stack, stack_stride, cn);
+                // A leaf does not stop the lane: it is parked in the lane's pending slot and the
+                // traversal goes on; parked leaves are tested together once enough lanes hold one.
+                if (trav && tv.ref < 0 && tv.ref != RT_TRAV_DONE && pend == 0) {
+                    pend = tv.ref;
+                    trav_pop(tv, stack, stack_stride);
+                }
+            }
+            const bool blocked = trav && tv.ref < 0 && tv.ref != RT_TRAV_DONE; // second leaf, slot taken
+            const bool has_pend = trav && pend != 0;
+            unsigned long long pmask = __ballot(has_pend);
+            if (pmask != 0ull) {
+                unsigned long long imask = __ballot(trav && tv.ref >= 0);
+                unsigned long long bmask = __ballot(blocked);
+                if (__popcll(pmask) >= leaf_min || __popcll(bmask) >= blocked_min || imask == 0ull) {
                     if constexpr (COUNT) {
                         w_l_iters++;
-                        w_l_lanes += __popcll(lmask);
+                        w_l_lanes += __popcll(pmask);
                     }
-                    if (at_leaf) {
-                        trav_test_leaf<COUNT>(tv, tv.ref, sc, vw, ps.ray, 0.001f, cn);
-                        trav_pop(tv, stack, stack_stride);
+                    if (has_pend) {
+                        trav_test_leaf<COUNT>(tv, pend, sc, vw, ps.ray, 0.001f, cn);
+                        pend = 0;
+                        if (blocked) {
+                            pend = tv.ref;
+                            trav_pop(tv, stack, stack_stride);
+                        }
                     }
                 }
             }
-            if (state == ST_TRAV && tv.ref == RT_TRAV_DONE) state = ST_READY;
+            if (trav && tv.ref == RT_TRAV_DONE && pend == 0) state = ST_READY;
         }
     }
     if constexpr (COUNT) {
@@ -441,6 +513,8 @@ hipError_t launch_mega(const DevScene &sc, const DevCamera &cam, const RenderPar
     return lg.lds_scene ? launch_mega_bvh_tc<true>(sc, cam, rp, lg, stream)
                         : launch_mega_bvh_tc<false>(sc, cam, rp, lg, stream);
 }
+
+int mega_waves_per_simd() { return RT_MEGA_WAVES_PER_SIMD; }
 
 hipError_t set_mega_lds_limit(int bytes) {
     hipError_t e = hipSuccess;

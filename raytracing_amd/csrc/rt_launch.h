@@ -6,6 +6,9 @@
 #include "rt_core.h"
 
 #define RT_MEGA_MAX_THREADS 1024
+#ifndef RT_MEGA_WAVES_PER_SIMD
+#define RT_MEGA_WAVES_PER_SIMD 4
+#endif
 #define RT_TRACE_THREADS 256
 #define RT_POOL_SAMPLES 4u // a wave reserves 64 pixels x this many samples from the global counter
 
@@ -21,7 +24,9 @@ struct RenderParams {
     rtc::Counters *counters;       // non-null: count tests (instrumented kernel variant)
     int scheduler; // BVH scenes: 0 = one whole ray per wave iteration, 1 = decoupled traverse / shade
     int min_ready; // decoupled: lanes that must wait for shading before traversal is interrupted
-    int leaf_min;  // decoupled: lanes that must wait at a leaf before the leaf block runs
+    int leaf_min;  // decoupled: lanes that must hold a parked leaf before the leaf block runs
+    int blocked_min; // decoupled: ... or this many lanes stalled on a second leaf
+    int regen_min;   // decoupled: idle lanes that must accumulate before new paths are started
 };
 
 struct LaunchGeom {
@@ -34,6 +39,7 @@ namespace rtl {
 hipError_t launch_mega(const rtc::DevScene &sc, const rtc::DevCamera &cam, const RenderParams &rp,
                        const LaunchGeom &lg, hipStream_t stream);
 hipError_t set_mega_lds_limit(int bytes);
+int mega_waves_per_simd(); // register budget the render kernels were compiled for
 hipError_t launch_reduce(const rtc::f4 *stage, int n_pixels, int sample_count, float *accum,
                          unsigned long long *ray_count, hipStream_t stream);
 hipError_t launch_trace(const rtc::DevScene &sc, const rt_ray *rays, long long n, float tmin, float tmax,

@@ -3,11 +3,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from raytracing_amd import abi, binding
 G = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 scene = sys.argv[1] if len(sys.argv) > 1 else "bouncing_spheres"
+spp = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 arrays = abi.SceneArrays.load(f"{G}/{scene}.rtscene"); cam, _ = abi.load_camera_file(f"{G}/{scene}.cam")
 sc = binding.Scene(arrays)
-acc, st = sc.render(cam, 100, counters=True)
+acc, st = sc.render(cam, spp, counters=True)
+acc, st0 = sc.render(cam, spp)
 s = list(st.sched)
 w = st.rays / 64
-print(f"rays {st.rays} box/ray {st.box_tests/st.rays:.1f} prim/ray {(st.sphere_tests+st.quad_tests)/st.rays:.2f} kernel_ms {st.kernel_ms:.3f}")
-if s[0]:
+print(f"{scene}: rays {st.rays} box/ray {st.box_tests/st.rays:.1f} prim/ray {(st.sphere_tests+st.quad_tests)/st.rays:.2f} kernel_ms {st0.kernel_ms:.3f} (instrumented {st.kernel_ms:.3f})")
+if os.environ.get("RT_AMD_SCHEDULER", "0") == "1" and s[0]:
     print(f"inner blocks {s[0]} ({s[0]/w:.1f} per 64 rays) active {s[1]/s[0]:.1f}/64 | leaf blocks {s[2]} ({s[2]/w:.1f} per 64 rays) active {s[3]/max(s[2],1):.1f}/64 | shade phases {s[4]} ({s[4]/w:.2f} per 64 rays) lanes {s[5]/max(s[4],1):.1f}/64")
+elif s[0]:
+    tot = s[0]
+    print(f"wave cycles: trace {s[1]/tot:.3f} shade {s[2]/tot:.3f} rest(regen, loop) {(tot-s[1]-s[2])/tot:.3f} | wave iterations {s[3]} ({s[3]/w:.2f} per 64 rays) live lanes {s[4]/max(s[3],1):.1f}/64 | cycles/iter trace {s[1]/s[3]:.0f} shade {s[2]/s[3]:.0f} rest {(tot-s[1]-s[2])/s[3]:.0f}")
