@@ -115,21 +115,22 @@ class Scene:
                                    hits.ctypes.data))
         return hits
 
-    def render(self, cam, sample_count, sample_begin=0, seed=0, counters=False, accum=None):
+    def render(self, cam, sample_count, sample_begin=0, seed=0, counters=False, accum=None,
+               mode=abi.RT_MODE_MEGAKERNEL):
         """Host-buffer render: returns (accum[H,W,3] fp32 sums, RenderStats)."""
         H, W = cam.image_height(), cam.image_width
         if accum is None:
             accum = np.zeros((H, W, 3), np.float32)
-        o = abi.RenderOpts(sample_begin, sample_count, seed, abi.RT_MODE_MEGAKERNEL,
+        o = abi.RenderOpts(sample_begin, sample_count, seed, mode,
                            abi.RT_RENDER_COUNTERS if counters else 0)
         st = abi.RenderStats()
         check(lib().rt_render(self.handle, C.byref(cam), C.byref(o), accum.ctypes.data, C.byref(st)))
         return accum, st
 
     def render_device(self, cam, sample_count, d_accum_ptr, stream=0, sample_begin=0, seed=0,
-                      counters=False, want_stats=False):
+                      counters=False, want_stats=False, mode=abi.RT_MODE_MEGAKERNEL):
         """Device-buffer render: d_accum_ptr is a device address (e.g. tensor.data_ptr())."""
-        o = abi.RenderOpts(sample_begin, sample_count, seed, abi.RT_MODE_MEGAKERNEL,
+        o = abi.RenderOpts(sample_begin, sample_count, seed, mode,
                            abi.RT_RENDER_COUNTERS if counters else 0)
         st = abi.RenderStats() if (want_stats or counters) else None
         check(lib().rt_render_device(self.handle, C.byref(cam), C.byref(o), C.c_void_p(d_accum_ptr),

@@ -63,6 +63,11 @@ struct rt_scene {
     rtc::Counters *d_counters = nullptr;
     int n_cu = 256;
     LaunchGeom geom; // persistent render kernel: grid, block, LDS bytes, what is staged
+    // wavefront variant: path-state arrays and queues (allocated on first use)
+    void *wf_mem = nullptr;
+    unsigned wf_slots = 0;
+    WfBuffers wf;
+    unsigned *wf_host_cnt = nullptr; // pinned
     // optional per-launch timing of the render kernel
     bool profiling = false;
     std::vector<hipEvent_t> prof_events; // pairs
@@ -218,6 +223,8 @@ int rt_scene_destroy(rt_scene *s) {
     hipSetDevice(s->device);
     for (void *p : s->allocs) hipFree(p);
     if (s->stage) hipFree(s->stage);
+    if (s->wf_mem) hipFree(s->wf_mem);
+    if (s->wf_host_cnt) hipHostFree(s->wf_host_cnt);
     for (hipEvent_t e : s->prof_events) hipEventDestroy(e);
     delete s;
     return RT_OK;
@@ -301,6 +308,7 @@ int rt_scene_create(const rt_scene_desc *d, int device, uint32_t flags, rt_scene
     if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n_cu > 0)
         s->n_cu = n_cu;
     hipError_t e = rtl::set_mega_lds_limit(kMaxLdsBytes);
+    if (e == hipSuccess) e = rtl::set_wavefront_lds_limit(kMaxLdsBytes);
     if (e != hipSuccess) {
         rt_scene_destroy(s);
         return fail(RT_ERR_HIP, "cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
@@ -328,6 +336,39 @@ size_t stage_budget_bytes() {
     return std::max<size_t>(mb, 1) << 20;
 }
 
+// Path-state arrays and queues of the wavefront variant for `n_slots` paths in flight.
+int ensure_wavefront(rt_scene *s, unsigned n_slots) {
+    if (s->wf_mem && s->wf_slots >= n_slots) return RT_OK;
+    if (s->wf_mem) RT_HIP(hipFree(s->wf_mem));
+    s->wf_mem = nullptr;
+    s->wf_slots = 0;
+    const size_t n = n_slots;
+    const size_t bytes = n * RT_WF_BYTES_PER_SLOT + 256;
+    RT_HIP(hipMalloc(&s->wf_mem, bytes));
+    char *p = (char *)s->wf_mem;
+    auto take = [&](size_t b) {
+        char *q = p;
+        p += b;
+        return (void *)q;
+    };
+    WfBuffers &w = s->wf;
+    w.ray_o = (f4 *)take(n * 16);
+    w.ray_d = (f4 *)take(n * 16);
+    w.thr = (f4 *)take(n * 16);
+    w.rad = (f4 *)take(n * 16);
+    w.hit_t = (float *)take(n * 4);
+    w.hit_slot = (int *)take(n * 4);
+    w.pix = (unsigned *)take(n * 4);
+    w.smp = (unsigned *)take(n * 4);
+    for (int k = 0; k < 2; k++) w.q_trace[k] = (int *)take(n * 4);
+    for (int k = 0; k < 5; k++) w.q_mat[k] = (int *)take(n * 4);
+    w.q_free = (int *)take(n * 4);
+    w.cnt = (unsigned *)take(64);
+    if (!s->wf_host_cnt) RT_HIP(hipHostMalloc((void **)&s->wf_host_cnt, 64, hipHostMallocDefault));
+    s->wf_slots = n_slots;
+    return RT_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -336,7 +377,11 @@ int rt_render_device(rt_scene *s, const rt_camera_desc *cam, const rt_render_opt
                      void *stream_v, rt_render_stats *stats) {
     if (!s || !cam || !opts || !d_accum) return fail(RT_ERR_ARG, "null argument");
     if (opts->sample_count < 0 || opts->sample_begin < 0) return fail(RT_ERR_ARG, "negative sample range");
-    if (opts->mode != RT_MODE_MEGAKERNEL) return fail(RT_ERR_UNSUPPORTED, "render mode %d not available", opts->mode);
+    if (opts->mode != RT_MODE_MEGAKERNEL && opts->mode != RT_MODE_WAVEFRONT)
+        return fail(RT_ERR_UNSUPPORTED, "render mode %d not available", opts->mode);
+    const bool wavefront = opts->mode == RT_MODE_WAVEFRONT;
+    if (wavefront && (opts->flags & RT_RENDER_COUNTERS))
+        return fail(RT_ERR_UNSUPPORTED, "the wavefront variant has no instrumented build");
     if (cam->max_depth < 0) return fail(RT_ERR_ARG, "negative max_depth");
     int rc = set_device(s->device);
     if (rc != RT_OK) return rc;
@@ -373,6 +418,16 @@ int rt_render_device(rt_scene *s, const rt_camera_desc *cam, const rt_render_opt
 
     const bool count = (opts->flags & RT_RENDER_COUNTERS) != 0 && stats != nullptr;
     const LaunchGeom lg = s->geom;
+    unsigned wf_slots = 0;
+    int wf_rounds = 0;
+    if (wavefront) {
+        // paths in flight: enough to fill the GPU many times over, bounded so that the state
+        // (about 110 bytes per slot) stays a small part of HBM
+        size_t want = std::min<size_t>((size_t)n_pixels * chunk, (size_t)std::max(1, env_int("RT_AMD_WF_SLOTS", 1 << 21)));
+        wf_slots = (unsigned)((want + 255) / 256 * 256);
+        rc = ensure_wavefront(s, wf_slots);
+        if (rc != RT_OK) return rc;
+    }
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (stats) {
         RT_HIP(hipEventCreate(&ev0));
@@ -408,7 +463,15 @@ int rt_render_device(rt_scene *s, const rt_camera_desc *cam, const rt_render_opt
             RT_HIP(hipEventRecord(p0, stream));
         }
         if (stats) RT_HIP(hipEventRecord(ev0, stream));
-        RT_HIP(rtl::launch_mega(s->dev, dc, rp, lg, stream));
+        if (!wavefront) {
+            RT_HIP(rtl::launch_mega(s->dev, dc, rp, lg, stream));
+        } else if (dc.max_depth <= 0) { // camera.h:141: every path is black
+            RT_HIP(hipMemsetAsync(s->stage, 0, per_sample * sc_n, stream));
+        } else {
+            int rounds = 0;
+            RT_HIP(rtl::render_wavefront(s->dev, dc, rp, s->wf, wf_slots, lg, s->wf_host_cnt, stream, &rounds));
+            wf_rounds += rounds;
+        }
         if (stats) RT_HIP(hipEventRecord(ev1, stream));
         if (s->profiling) {
             RT_HIP(hipEventRecord(p1, stream));
@@ -432,6 +495,7 @@ int rt_render_device(rt_scene *s, const rt_camera_desc *cam, const rt_render_opt
         stats->paths = (uint64_t)n_pixels * (uint64_t)opts->sample_count;
         stats->rays = rays;
         stats->kernel_ms = mega_ms;
+        if (wavefront) stats->sched[0] = (uint64_t)wf_rounds;
         if (count) {
             rtc::Counters c;
             RT_HIP(hipMemcpy(&c, s->d_counters, sizeof(c), hipMemcpyDeviceToHost));
