@@ -352,14 +352,9 @@ int ensure_wavefront(rt_scene *s, unsigned n_slots) {
         return (void *)q;
     };
     WfBuffers &w = s->wf;
-    w.ray_o = (f4 *)take(n * 16);
-    w.ray_d = (f4 *)take(n * 16);
-    w.thr = (f4 *)take(n * 16);
-    w.rad = (f4 *)take(n * 16);
-    w.hit_t = (float *)take(n * 4);
-    w.hit_slot = (int *)take(n * 4);
-    w.pix = (unsigned *)take(n * 4);
-    w.smp = (unsigned *)take(n * 4);
+    w.state = (f4 *)take(n * 64);
+    w.aux = (rtc::i4 *)take(n * 16);
+    w.key = (int *)take(n * 4);
     for (int k = 0; k < 2; k++) w.q_trace[k] = (int *)take(n * 4);
     for (int k = 0; k < 5; k++) w.q_mat[k] = (int *)take(n * 4);
     w.q_free = (int *)take(n * 4);

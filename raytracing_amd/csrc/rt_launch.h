@@ -37,20 +37,16 @@ struct LaunchGeom {
 
 // Path state of the wavefront variant: structure-of-arrays over the in-flight path slots.
 struct WfBuffers {
-    rtc::f4 *ray_o;  // {origin, time}
-    rtc::f4 *ray_d;  // {direction, -}
-    rtc::f4 *thr;    // {throughput, sampler state}
-    rtc::f4 *rad;    // {radiance so far, bounces left | rays traced << 16}
-    float *hit_t;    // closest hit of the queued ray
-    int *hit_slot;
-    unsigned *pix;   // pixel and local sample index of the path in the slot
-    unsigned *smp;
+    rtc::f4 *state;  // 64 bytes per slot: {origin, time} {direction, -} {throughput, sampler state}
+                     //                    {radiance so far, bounces left | rays traced << 16}
+    rtc::i4 *aux;    // 16 bytes per slot: {hit t, hit slot, pixel, local sample index}
+    int *key;        // per queue position: queue the traced ray goes to
     int *q_trace[2]; // rays to trace this round / next round
     int *q_mat[5];   // hits by material (lambertian, metal, dielectric, light) and misses
     int *q_free;     // slots without a path
     unsigned *cnt;   // 16 counters (queue lengths, pool position, finished paths)
 };
-#define RT_WF_BYTES_PER_SLOT (4 * 16 + 4 * 4 + 8 * 4)
+#define RT_WF_BYTES_PER_SLOT (64 + 16 + 4 + 8 * 4)
 
 namespace rtl {
 hipError_t set_wavefront_lds_limit(int bytes);

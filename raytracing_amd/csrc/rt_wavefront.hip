@@ -5,16 +5,16 @@
 //
 //   wf_prep      1 thread   : rotates the queue counters for the round
 //   wf_generate  1 lane/slot: starts new camera paths in the path slots freed last round
-//   wf_trace     persistent : closest hit for every queued ray (geometry staged in LDS); each
-//                             ray is then appended to the queue of the material it hit (or to
-//                             the miss queue) with one atomic per wave per queue
+//   wf_trace     persistent : closest hit for every queued ray (geometry staged in LDS)
+//   wf_classify  1 lane/ray : appends each traced ray to the queue of the material it hit (or
+//                             to the miss queue), one global atomic per workgroup per queue
 //   wf_shade     1 lane/hit : walks the material queues back to back, so that a wave shades one
 //                             material; continuing paths are queued for the next round,
 //                             finished ones write their radiance record and free their slot
 //
 // It exists to be compared with the megakernel (same images, see tests/test_gpu_wavefront.py):
 // coherent shading and a trace kernel free of shading registers, paid for with ~200 bytes of
-// HBM traffic per ray and four launches per bounce.
+// HBM traffic per ray and six launches per bounce.
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
@@ -30,114 +30,147 @@ namespace {
 enum { Q_LAMBERTIAN = 0, Q_METAL = 1, Q_DIELECTRIC = 2, Q_LIGHT = 3, Q_MISS = 4, N_QUEUES = 5 };
 // counters (unsigned words)
 enum {
-    C_TRACE_CUR = 0, // rays queued for this round
-    C_TRACE_NEXT = 1,
-    C_Q0 = 2,        // .. C_Q0 + 4: material / miss queues
-    C_FREE = 7,      // path slots freed during this round's shading
-    C_FREE_SNAP = 8, // free slots the generator may fill this round
-    C_POOL = 9,      // next path index to start
-    C_DONE = 10      // finished paths
+    C_TRACE_CUR = 0,  // rays queued for this round
+    C_TRACE_NEXT = 1, // rays queued for the next round (written by the shading kernel) ...
+    C_FREE = 2,       // ... and, next to it, the path slots that kernel freed
+    C_Q0 = 3,         // .. C_Q0 + 4: material / miss queues
+    C_FREE_SNAP = 8,  // free slots the generator looks at this round
+    C_POOL = 9,       // next path index to start
+    C_DONE = 10,      // finished paths (up to the previous round)
+    C_GEN_BASE = 11,  // rays carried over from shading: the generator appends behind them
+    C_GEN_COUNT = 12  // paths the generator starts this round
 };
 
 __device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63u; }
 
-// Appends `item` to queue `q` for the lanes with pred == true: one atomic per wave.
-__device__ __forceinline__ void wave_push(int *q, unsigned *counter, bool pred, int item) {
-    unsigned long long m = __ballot(pred);
-    if (m == 0ull) return;
-    unsigned base = 0;
-    unsigned leader = (unsigned)__builtin_ctzll(m);
-    if (lane_id() == leader) base = atomicAdd(counter, (unsigned)__popcll(m));
-    base = __shfl(base, (int)leader, 64);
-    if (pred) q[base + (unsigned)__popcll(m & ((1ull << lane_id()) - 1ull))] = item;
+// Appends `item` to queue q[key] (key < 0: nothing) for a whole workgroup with ONE global atomic
+// per non-empty queue: atomics on a single address are the scarce resource of queue-based
+// schedulers (about 10 ns each on this GPU).  Every thread of the workgroup must call it.
+// `lds` holds 2 * NQ words.
+template <int NQ>
+__device__ __forceinline__ void block_push(int *const (&q)[NQ], unsigned *counters, int key, int item,
+                                           unsigned *lds) {
+    if (threadIdx.x < NQ) lds[threadIdx.x] = 0;
+    __syncthreads();
+    unsigned my_off = 0;
+    const unsigned long long lt = (1ull << lane_id()) - 1ull;
+#pragma unroll
+    for (int k = 0; k < NQ; k++) {
+        unsigned long long m = __ballot(key == k);
+        if (m != 0ull) {
+            unsigned w = 0;
+            unsigned leader = (unsigned)__builtin_ctzll(m);
+            if (lane_id() == leader) w = atomicAdd(&lds[k], (unsigned)__popcll(m));
+            w = __shfl(w, (int)leader, 64);
+            if (key == k) my_off = w + (unsigned)__popcll(m & lt);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < NQ) {
+        unsigned c = lds[threadIdx.x];
+        lds[NQ + threadIdx.x] = c ? atomicAdd(&counters[threadIdx.x], c) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NQ; k++)
+        if (key == k) q[k][lds[NQ + k] + my_off] = item;
+    __syncthreads();
 }
 
-__global__ void wf_prep(unsigned *cnt) {
-    cnt[C_TRACE_CUR] = cnt[C_TRACE_NEXT];
+__global__ void wf_prep(unsigned *cnt, unsigned total_paths) {
+    cnt[C_DONE] += cnt[C_FREE];
+    unsigned carried = cnt[C_TRACE_NEXT];
+    unsigned n_free = cnt[C_FREE_SNAP] = cnt[C_FREE];
+    unsigned left = total_paths - cnt[C_POOL];
+    unsigned n_new = n_free < left ? n_free : left;
+    cnt[C_GEN_BASE] = carried;
+    cnt[C_GEN_COUNT] = n_new;
+    cnt[C_TRACE_CUR] = carried + n_new;
     cnt[C_TRACE_NEXT] = 0;
-    for (int k = 0; k < N_QUEUES; k++) cnt[C_Q0 + k] = 0;
-    cnt[C_FREE_SNAP] = cnt[C_FREE];
     cnt[C_FREE] = 0;
+    for (int k = 0; k < N_QUEUES; k++) cnt[C_Q0 + k] = 0;
 }
 
+// Thread i starts path number pool + i in the i-th free slot.  No atomics: wf_prep has
+// already reserved the queue space and wf_advance moves the pool position afterwards.
+// Free slots beyond the paths that are left are dropped (nothing will need them again).
 __global__ void __launch_bounds__(256)
-wf_generate(DevCamera cam, RenderParams rp, WfBuffers wf, unsigned total_paths, int *q_trace_cur) {
+wf_generate(DevCamera cam, RenderParams rp, WfBuffers wf, int *q_trace_cur) {
     unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    bool have_slot = i < wf.cnt[C_FREE_SNAP];
-    // one pool ticket per lane that owns a free slot (wave-aggregated)
-    unsigned long long m = __ballot(have_slot);
-    unsigned base = 0;
-    if (m != 0ull) {
-        unsigned leader = (unsigned)__builtin_ctzll(m);
-        if (lane_id() == leader) base = atomicAdd(&wf.cnt[C_POOL], (unsigned)__popcll(m));
-        base = __shfl(base, (int)leader, 64);
-    }
-    unsigned p = base + (unsigned)__popcll(m & ((1ull << lane_id()) - 1ull));
-    bool start = have_slot && p < total_paths;
-    int slot = have_slot ? wf.q_free[i] : 0;
-    if (start) {
-        // paths are numbered sample-major: consecutive lanes take consecutive pixels
-        unsigned s_local = p / (unsigned)rp.n_pixels;
-        unsigned pixel = p - s_local * (unsigned)rp.n_pixels;
-        int py = (int)(pixel / (unsigned)rp.width);
-        int px = (int)(pixel - (unsigned)py * (unsigned)rp.width);
-        PathState ps = path_start(cam, rp.seed, pixel, px, py, (unsigned)rp.sample_begin + s_local);
-        wf.ray_o[slot] = f4{ps.ray.o.x, ps.ray.o.y, ps.ray.o.z, ps.ray.tm};
-        wf.ray_d[slot] = f4{ps.ray.d.x, ps.ray.d.y, ps.ray.d.z, 0.0f};
-        wf.thr[slot] = f4{1.0f, 1.0f, 1.0f, __builtin_bit_cast(float, ps.rng.s)};
-        wf.rad[slot] = f4{0.0f, 0.0f, 0.0f, __builtin_bit_cast(float, (unsigned)ps.depth)};
-        wf.pix[slot] = pixel;
-        wf.smp[slot] = s_local;
-    }
-    // a slot that finds no path (pool exhausted) is dropped: nothing will need it again
-    wave_push(q_trace_cur, &wf.cnt[C_TRACE_CUR], start, slot);
+    if (i >= wf.cnt[C_GEN_COUNT]) return;
+    unsigned p = wf.cnt[C_POOL] + i;
+    int slot = wf.q_free[i];
+    // paths are numbered sample-major: consecutive lanes take consecutive pixels
+    unsigned s_local = p / (unsigned)rp.n_pixels;
+    unsigned pixel = p - s_local * (unsigned)rp.n_pixels;
+    int py = (int)(pixel / (unsigned)rp.width);
+    int px = (int)(pixel - (unsigned)py * (unsigned)rp.width);
+    PathState ps = path_start(cam, rp.seed, pixel, px, py, (unsigned)rp.sample_begin + s_local);
+    f4 *st = wf.state + 4 * (size_t)slot;
+    st[0] = f4{ps.ray.o.x, ps.ray.o.y, ps.ray.o.z, ps.ray.tm};
+    st[1] = f4{ps.ray.d.x, ps.ray.d.y, ps.ray.d.z, 0.0f};
+    st[2] = f4{1.0f, 1.0f, 1.0f, __builtin_bit_cast(float, ps.rng.s)};
+    st[3] = f4{0.0f, 0.0f, 0.0f, __builtin_bit_cast(float, (unsigned)ps.depth)};
+    wf.aux[slot] = i4{0, -1, (int)pixel, (int)s_local};
+    q_trace_cur[wf.cnt[C_GEN_BASE] + i] = slot;
 }
 
-// Persistent: one workgroup per CU stages the geometry into LDS once per launch and walks the
-// ray queue with a grid stride; one whole ray per lane per iteration.
+__global__ void wf_advance(unsigned *cnt) { cnt[C_POOL] += cnt[C_GEN_COUNT]; }
+
+// Persistent: one workgroup per CU stages the geometry into LDS once per launch; its waves
+// take batches of 64 queued rays with a grid stride, one whole ray per lane.  Writes the hit
+// and, per queue position, the key of the queue the ray goes to next.
 template <int TRAV, bool LDS_SCENE>
 __global__ void __launch_bounds__(RT_MEGA_MAX_THREADS, RT_MEGA_WAVES_PER_SIMD)
 wf_trace(DevScene sc, WfBuffers wf, const int *q_trace_cur) {
     extern __shared__ f4 smem[];
     SceneView vw = global_view(sc);
     f4 *free_lds = smem;
+    const unsigned n = wf.cnt[C_TRACE_CUR];
+    if (blockIdx.x * blockDim.x >= n) return; // nothing for this workgroup: skip the staging
     if constexpr (LDS_SCENE) free_lds = stage_scene(sc, smem, vw);
     using StackT = typename std::conditional<LDS_SCENE, short, int>::type;
     StackT *stack = reinterpret_cast<StackT *>(free_lds) + threadIdx.x;
     const int stack_stride = blockDim.x;
-    const unsigned n = wf.cnt[C_TRACE_CUR];
     Cnt<false> cn;
-    // whole waves iterate together so that the wave-aggregated pushes see every lane
+    const unsigned stride = gridDim.x * blockDim.x;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        int slot = q_trace_cur[i];
+        const f4 *st = wf.state + 4 * (size_t)slot;
+        f4 o = st[0], d = st[1];
+        Ray r;
+        r.o = mk(o.x, o.y, o.z);
+        r.d = mk(d.x, d.y, d.z);
+        r.tm = o.w;
+        TraceHit h;
+        if constexpr (TRAV == TRAV_LINEAR)
+            h = trace_linear<false>(sc, vw, r, 0.001f, RT_INF, cn);
+        else
+            h = trace_bvh<false, StackT>(sc, vw, r, 0.001f, RT_INF, stack, stack_stride, cn);
+        // the first 8 bytes of the auxiliary record: {t, slot}
+        *reinterpret_cast<float2 *>(&wf.aux[slot]) = float2{h.t, __builtin_bit_cast(float, h.slot)};
+        wf.key[i] = h.slot < 0 ? (int)Q_MISS : RT_KIND_MAT(vw.rec_i[h.slot].x);
+    }
+}
+
+// Distributes the traced rays over the material queues.
+__global__ void __launch_bounds__(1024) wf_classify(WfBuffers wf, const int *q_trace_cur) {
+    __shared__ unsigned lds[2 * N_QUEUES];
+    const unsigned n = wf.cnt[C_TRACE_CUR];
+    int *const q[N_QUEUES] = {wf.q_mat[0], wf.q_mat[1], wf.q_mat[2], wf.q_mat[3], wf.q_mat[4]};
     const unsigned stride = gridDim.x * blockDim.x;
     for (unsigned base = blockIdx.x * blockDim.x; base < n; base += stride) {
         unsigned i = base + threadIdx.x;
         bool live = i < n;
-        int slot = live ? q_trace_cur[i] : 0;
-        int q = -1;
-        if (live) {
-            f4 o = wf.ray_o[slot], d = wf.ray_d[slot];
-            Ray r;
-            r.o = mk(o.x, o.y, o.z);
-            r.d = mk(d.x, d.y, d.z);
-            r.tm = o.w;
-            TraceHit h;
-            if constexpr (TRAV == TRAV_LINEAR)
-                h = trace_linear<false>(sc, vw, r, 0.001f, RT_INF, cn);
-            else
-                h = trace_bvh<false, StackT>(sc, vw, r, 0.001f, RT_INF, stack, stack_stride, cn);
-            wf.hit_t[slot] = h.t;
-            wf.hit_slot[slot] = h.slot;
-            q = h.slot < 0 ? (int)Q_MISS : RT_KIND_MAT(vw.rec_i[h.slot].x);
-        }
-#pragma unroll
-        for (int k = 0; k < N_QUEUES; k++) wave_push(wf.q_mat[k], &wf.cnt[C_Q0 + k], q == k, slot);
+        block_push<N_QUEUES>(q, &wf.cnt[C_Q0], live ? wf.key[i] : -1, live ? q_trace_cur[i] : 0, lds);
     }
 }
 
 // The material queues are walked back to back: lane i finds its queue by the running
 // totals, so a wave shades one material except where two queues meet.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 wf_shade(DevScene sc, DevCamera cam, RenderParams rp, WfBuffers wf, int *q_trace_next) {
+    __shared__ unsigned lds[4];
     const SceneView vw = global_view(sc);
     unsigned c[N_QUEUES], total = 0;
 #pragma unroll
@@ -145,12 +178,14 @@ wf_shade(DevScene sc, DevCamera cam, RenderParams rp, WfBuffers wf, int *q_trace
         c[k] = wf.cnt[C_Q0 + k];
         total += c[k];
     }
+    int *const out[2] = {q_trace_next, wf.q_free};
     Cnt<false> cn;
     const unsigned stride = gridDim.x * blockDim.x;
     for (unsigned base = blockIdx.x * blockDim.x; base < total; base += stride) {
         unsigned i = base + threadIdx.x;
         bool live = i < total;
         int slot = 0;
+        int key = -1;
         if (live) {
             unsigned j = i;
             int k = 0;
@@ -160,10 +195,9 @@ wf_shade(DevScene sc, DevCamera cam, RenderParams rp, WfBuffers wf, int *q_trace
             }
             const int *q = k == 0 ? wf.q_mat[0] : k == 1 ? wf.q_mat[1] : k == 2 ? wf.q_mat[2] : k == 3 ? wf.q_mat[3] : wf.q_mat[4];
             slot = q[j];
-        }
-        bool cont = false, done = false;
-        if (live) {
-            f4 o = wf.ray_o[slot], d = wf.ray_d[slot], th = wf.thr[slot], ra = wf.rad[slot];
+            f4 *st = wf.state + 4 * (size_t)slot;
+            f4 o = st[0], d = st[1], th = st[2], ra = st[3];
+            const i4 ax = wf.aux[slot];
             PathState ps;
             ps.ray.o = mk(o.x, o.y, o.z);
             ps.ray.d = mk(d.x, d.y, d.z);
@@ -175,26 +209,23 @@ wf_shade(DevScene sc, DevCamera cam, RenderParams rp, WfBuffers wf, int *q_trace
             ps.depth = (int)(packed & 0xffffu);
             unsigned n_rays = (packed >> 16) + 1u;
             TraceHit h;
-            h.t = wf.hit_t[slot];
-            h.slot = wf.hit_slot[slot];
-            cont = path_after_trace<false>(sc, vw, cam, ps, h, cn);
-            if (cont) {
-                wf.ray_o[slot] = f4{ps.ray.o.x, ps.ray.o.y, ps.ray.o.z, ps.ray.tm};
-                wf.ray_d[slot] = f4{ps.ray.d.x, ps.ray.d.y, ps.ray.d.z, 0.0f};
-                wf.thr[slot] = f4{ps.beta.x, ps.beta.y, ps.beta.z, __builtin_bit_cast(float, ps.rng.s)};
-                wf.rad[slot] = f4{ps.L.x, ps.L.y, ps.L.z,
-                                  __builtin_bit_cast(float, ((unsigned)ps.depth & 0xffffu) | (n_rays << 16))};
+            h.t = __builtin_bit_cast(float, ax.x);
+            h.slot = ax.y;
+            if (path_after_trace<false>(sc, vw, cam, ps, h, cn)) {
+                key = 0;
+                st[0] = f4{ps.ray.o.x, ps.ray.o.y, ps.ray.o.z, ps.ray.tm};
+                st[1] = f4{ps.ray.d.x, ps.ray.d.y, ps.ray.d.z, 0.0f};
+                st[2] = f4{ps.beta.x, ps.beta.y, ps.beta.z, __builtin_bit_cast(float, ps.rng.s)};
+                st[3] = f4{ps.L.x, ps.L.y, ps.L.z,
+                           __builtin_bit_cast(float, ((unsigned)ps.depth & 0xffffu) | (n_rays << 16))};
             } else {
-                done = true;
-                unsigned pixel = wf.pix[slot], s_local = wf.smp[slot];
+                key = 1;
+                unsigned pixel = (unsigned)ax.z, s_local = (unsigned)ax.w;
                 rp.stage[(size_t)s_local * (size_t)rp.n_pixels + pixel] =
                     f4{ps.L.x, ps.L.y, ps.L.z, __builtin_bit_cast(float, n_rays)};
             }
         }
-        wave_push(q_trace_next, &wf.cnt[C_TRACE_NEXT], cont, slot);
-        wave_push(wf.q_free, &wf.cnt[C_FREE], done, slot);
-        unsigned long long dm = __ballot(done);
-        if (dm != 0ull && lane_id() == (unsigned)__builtin_ctzll(dm)) atomicAdd(&wf.cnt[C_DONE], (unsigned)__popcll(dm));
+        block_push<2>(out, &wf.cnt[C_TRACE_NEXT], key, slot, lds);
     }
 }
 
@@ -204,6 +235,8 @@ __global__ void wf_init(WfBuffers wf, unsigned n_slots) {
     if (i == 0) {
         for (int k = 0; k < 16; k++) wf.cnt[k] = 0;
         wf.cnt[C_FREE] = n_slots;
+        // wf_prep credits the freed slots of the previous round to the finished paths
+        wf.cnt[C_DONE] = 0u - n_slots;
     }
 }
 
@@ -231,14 +264,16 @@ hipError_t render_wavefront(const DevScene &sc, const DevCamera &cam, const Rend
                             int *rounds_out) {
     const unsigned total = (unsigned)rp.n_pixels * (unsigned)rp.sample_count;
     const int slot_grid = (int)((n_slots + 255) / 256);
+    const int big_grid = (int)((n_slots + 1023) / 1024);
     hipLaunchKernelGGL(wf_init, dim3(slot_grid), dim3(256), 0, stream, wf, n_slots);
     int rounds = 0;
     for (;;) {
         // a batch of rounds between two looks at the counters; a round advances every path by one bounce
         for (int k = 0; k < 8; k++, rounds++) {
             int *cur = wf.q_trace[rounds & 1], *next = wf.q_trace[(rounds + 1) & 1];
-            hipLaunchKernelGGL(wf_prep, dim3(1), dim3(1), 0, stream, wf.cnt);
-            hipLaunchKernelGGL(wf_generate, dim3(slot_grid), dim3(256), 0, stream, cam, rp, wf, total, cur);
+            hipLaunchKernelGGL(wf_prep, dim3(1), dim3(1), 0, stream, wf.cnt, total);
+            hipLaunchKernelGGL(wf_generate, dim3(slot_grid), dim3(256), 0, stream, cam, rp, wf, cur);
+            hipLaunchKernelGGL(wf_advance, dim3(1), dim3(1), 0, stream, wf.cnt);
             if (sc.traversal == TRAV_LINEAR) {
                 if (lg.lds_scene)
                     hipLaunchKernelGGL((wf_trace<TRAV_LINEAR, true>), dim3(lg.grid), dim3(lg.block), lg.lds_bytes, stream, sc, wf, cur);
@@ -250,7 +285,8 @@ hipError_t render_wavefront(const DevScene &sc, const DevCamera &cam, const Rend
                 else
                     hipLaunchKernelGGL((wf_trace<TRAV_BVH, false>), dim3(lg.grid), dim3(lg.block), lg.lds_bytes, stream, sc, wf, cur);
             }
-            hipLaunchKernelGGL(wf_shade, dim3(slot_grid), dim3(256), 0, stream, sc, cam, rp, wf, next);
+            hipLaunchKernelGGL(wf_classify, dim3(big_grid), dim3(1024), 0, stream, wf, cur);
+            hipLaunchKernelGGL(wf_shade, dim3(big_grid), dim3(1024), 0, stream, sc, cam, rp, wf, next);
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
@@ -258,7 +294,7 @@ hipError_t render_wavefront(const DevScene &sc, const DevCamera &cam, const Rend
         if (e != hipSuccess) return e;
         e = hipStreamSynchronize(stream);
         if (e != hipSuccess) return e;
-        if (host_cnt[C_DONE] >= total) break;
+        if (host_cnt[C_DONE] + host_cnt[C_FREE] >= total) break; // C_FREE: finished in the last round
         if (rounds > 100000) return hipErrorUnknown; // cannot happen: every round retires or advances paths
     }
     if (rounds_out) *rounds_out = rounds;
