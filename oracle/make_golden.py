@@ -65,6 +65,12 @@ def stage_pins():
         print(s, meta)
 
 
+# row bands per scene and the stretch of the random stream skipped per band index (bands use
+# disjoint stretches); finished bands are kept in BAND_DIR so that an interrupted run resumes
+IMAGE_BANDS = {"cornell_box": (24, 8_000_000_000)}
+BAND_DIR = os.path.join(tempfile.gettempdir(), "golden_bands")
+
+
 def stage_images(scenes, workers=6):
     from PIL import Image
     for s in scenes:
@@ -72,16 +78,26 @@ def stage_images(scenes, workers=6):
         info = run(["dump", s, os.devnull, os.path.join(tempfile.gettempdir(), "x.cam")])
         h, w = info["height"], info["width"]
         # split into row bands so that several processes share the work
-        n_bands = workers if h * w * spp > 2e8 else 1
+        n_bands, burn = IMAGE_BANDS.get(s, (workers if h * w * spp > 2e8 else 1, BAND_BURN))
         edges = [round(k * h / n_bands) for k in range(n_bands + 1)]
-        with tempfile.TemporaryDirectory() as td:
-            def job(k):
-                return run(["render", s, spp, k * BAND_BURN, edges[k], edges[k + 1], f"{td}/b{k}.f32"])
-            with ThreadPoolExecutor(workers) as ex:
-                metas = list(ex.map(job, range(n_bands)))
-            sums = np.zeros((h, w, 3), np.float32)
-            for k in range(n_bands):
-                sums += np.fromfile(f"{td}/b{k}.f32", np.float32).reshape(h, w, 3)
+        td = os.path.join(BAND_DIR, f"{s}_{spp}_{n_bands}")
+        os.makedirs(td, exist_ok=True)
+
+        def job(k):
+            meta_path = f"{td}/b{k}.json"
+            if os.path.exists(meta_path):
+                return json.load(open(meta_path))
+            m = run(["render", s, spp, k * burn, edges[k], edges[k + 1], f"{td}/b{k}.f32"])
+            with open(meta_path + ".tmp", "w") as f:
+                json.dump(m, f)
+            os.replace(meta_path + ".tmp", meta_path)
+            print(s, "band", k, "done", flush=True)
+            return m
+        with ThreadPoolExecutor(workers) as ex:
+            metas = list(ex.map(job, range(n_bands)))
+        sums = np.zeros((h, w, 3), np.float32)
+        for k in range(n_bands):
+            sums += np.fromfile(f"{td}/b{k}.f32", np.float32).reshape(h, w, 3)
         # write_color (color.h:17-32) exactly as the reference quantises: via the harness' own
         # u8 output for a single band, or restated here in fp32 for the merged image
         c = sums * np.float32(1.0 / spp)

@@ -11,7 +11,7 @@ acc, st0 = sc.render(cam, spp)
 s = list(st.sched)
 w = st.rays / 64
 print(f"{scene}: rays {st.rays} box/ray {st.box_tests/st.rays:.1f} prim/ray {(st.sphere_tests+st.quad_tests)/st.rays:.2f} kernel_ms {st0.kernel_ms:.3f} (instrumented {st.kernel_ms:.3f})")
-if os.environ.get("RT_AMD_SCHEDULER", "0") == "1" and s[0]:
+if os.environ.get("RT_AMD_SCHEDULER", "1") == "1" and s[0]:
     print(f"inner blocks {s[0]} ({s[0]/w:.1f} per 64 rays) active {s[1]/s[0]:.1f}/64 | leaf blocks {s[2]} ({s[2]/w:.1f} per 64 rays) active {s[3]/max(s[2],1):.1f}/64 | shade phases {s[4]} ({s[4]/w:.2f} per 64 rays) lanes {s[5]/max(s[4],1):.1f}/64")
 elif s[0]:
     tot = s[0]
