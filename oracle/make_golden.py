@@ -67,7 +67,7 @@ def stage_pins():
 
 # row bands per scene and the stretch of the random stream skipped per band index (bands use
 # disjoint stretches); finished bands are kept in BAND_DIR so that an interrupted run resumes
-IMAGE_BANDS = {"cornell_box": (24, 8_000_000_000)}
+IMAGE_BANDS = {"cornell_box": (30, 8_000_000_000), "simple_light": (24, 4_000_000_000)}
 BAND_DIR = os.path.join(tempfile.gettempdir(), "golden_bands")
 
 

@@ -80,7 +80,8 @@ struct Ray {
 // rec_f: per slot {r g b param}: lambertian / light with a solid texture: the colour;
 //   metal: albedo + fuzz; dielectric: (1,1,1) + refraction index
 // nodes: BVH2 with the two child boxes stored in the parent, 64 bytes:
-//   {lo0.x lo0.y lo0.z hi0.x} {hi0.y hi0.z lo1.x lo1.y} {lo1.z hi1.x hi1.y hi1.z} {ref0 ref1 - -}
+//   {c0.x c0.y c0.z h0.x} {h0.y h0.z c1.x c1.y} {c1.z h1.x h1.y h1.z} {ref0 ref1 - -}
+//   (c = centre, h = half extent of a child box)
 //   ref >= 0: inner node index; ref < 0: leaf, ~ref = slot*2 + type
 // textures: only the textures reachable from a non-solid material texture (re-indexed)
 // xf   : 3 x 16 bytes per wrapper op {type p0 p1 p2} {sa ca sb cb} {sg cg - -}
@@ -413,18 +414,25 @@ RT_HD BoxRay make_box_ray(const Ray &r) {
     b.e2 = 9.5367431640625e-7f * fmaxf(mx, fmaxf(my, mz));
     return b;
 }
-// Conservative ray/box overlap on [tmin, tmax]: returns the (slightly early) entry
-// parameter, or +inf when the box is missed.  Boxes are padded at build time.
-RT_HD float box_entry(f3 lo, f3 hi, const BoxRay &b, float tmin, float tmax) {
-    float ax = __builtin_fmaf(lo.x, b.inv.x, b.oi.x), bx = __builtin_fmaf(hi.x, b.inv.x, b.oi.x);
-    float ay = __builtin_fmaf(lo.y, b.inv.y, b.oi.y), by = __builtin_fmaf(hi.y, b.inv.y, b.oi.y);
-    float az = __builtin_fmaf(lo.z, b.inv.z, b.oi.z), bz = __builtin_fmaf(hi.z, b.inv.z, b.oi.z);
-    float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
-    float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
+// Conservative ray/box overlap on [tmin, tmax] for a box given as centre c and half extent
+// h: true if the box may be hit, tn = the (slightly early) entry parameter.  With
+// m = (c - o) / d per axis the slab is [m - h/|d|, m + h/|d|]: three FMAs per axis and no
+// per-axis min / max (v_min_f32 / v_max_f32 issue at half the rate of v_fma_f32 on gfx950).
+// Boxes are padded at build time.
+RT_HD bool box_hit(f3 c, f3 h, const BoxRay &b, float tmin, float tmax, float &tn) {
+    float mx = __builtin_fmaf(c.x, b.inv.x, b.oi.x);
+    float my = __builtin_fmaf(c.y, b.inv.y, b.oi.y);
+    float mz = __builtin_fmaf(c.z, b.inv.z, b.oi.z);
+    float ix = fabsf(b.inv.x), iy = fabsf(b.inv.y), iz = fabsf(b.inv.z);
+    float nx = __builtin_fmaf(-h.x, ix, mx), fx = __builtin_fmaf(h.x, ix, mx);
+    float ny = __builtin_fmaf(-h.y, iy, my), fy = __builtin_fmaf(h.y, iy, my);
+    float nz = __builtin_fmaf(-h.z, iz, mz), fz = __builtin_fmaf(h.z, iz, mz);
+    tn = fmaxf(fmaxf(nx, ny), fmaxf(nz, tmin));
+    float tf = fminf(fminf(fx, fy), fminf(fz, tmax));
     // exit parameter widened by the absolute slack (2e) and a relative one (2^-19 |tf|) for the
     // rounding of the fma results themselves; when the test is close, |tn| ~ |tf|
     float tf_wide = __builtin_fmaf(1.9073486328125e-6f, fabsf(tf), tf + b.e2);
-    return (tn <= tf_wide) ? tn : RT_INF;
+    return tn <= tf_wide;
 }
 
 #ifndef RT_STACK_DEPTH
@@ -467,10 +475,10 @@ RT_HD void trav_inner(Trav &tv, const f4 *nodes, float tmin, StackT *stack, int 
     const f4 *n = nodes + (size_t)tv.ref * 4;
     f4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
     if constexpr (COUNT) cn.box += 2;
-    float e0 = box_entry(mk(n0.x, n0.y, n0.z), mk(n0.w, n1.x, n1.y), tv.br, tmin, tv.best_t);
-    float e1 = box_entry(mk(n1.z, n1.w, n2.x), mk(n2.y, n2.z, n2.w), tv.br, tmin, tv.best_t);
+    float e0, e1;
+    bool h0 = box_hit(mk(n0.x, n0.y, n0.z), mk(n0.w, n1.x, n1.y), tv.br, tmin, tv.best_t, e0);
+    bool h1 = box_hit(mk(n1.z, n1.w, n2.x), mk(n2.y, n2.z, n2.w), tv.br, tmin, tv.best_t, e1);
     int r0 = __builtin_bit_cast(int, n3.x), r1 = __builtin_bit_cast(int, n3.y);
-    bool h0 = e0 < RT_INF, h1 = e1 < RT_INF;
     // selects instead of a three-way branch: the nearer hit child is visited next, the other
     // hit child (if any) is pushed; only "no child hit" needs the stack read
     bool second_first = h1 && (!h0 || e1 < e0);

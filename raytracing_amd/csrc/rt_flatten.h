@@ -125,6 +125,19 @@ void pad_box(Box3 &b) {
     }
 }
 
+// Centre and half extent of a box; centre - half <= lo and centre + half >= hi hold exactly.
+inline void center_half(const Box3 &b, float *c, float *h) {
+    for (int k = 0; k < 3; k++) {
+        double lo = b.lo[k], hi = b.hi[k];
+        float cf = (float)(0.5 * (lo + hi));
+        double need = std::max(hi - (double)cf, (double)cf - lo);
+        float hf = (float)need;
+        while ((double)hf < need) hf = std::nextafter(hf, INFINITY);
+        c[k] = cf;
+        h[k] = hf;
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // Binned-SAH BVH2 builder.  Leaves hold one primitive; a parent stores the boxes
 // of both children (one 64-byte fetch tests both).
@@ -186,9 +199,14 @@ class BvhBuilder {
         int r0 = build(first, mid - first, depth + 1, b0);
         int r1 = build(mid, first + count - mid, depth + 1, b1);
         f4 *n = &out_.nodes[(size_t)node * 4];
-        n[0] = f4{b0.lo[0], b0.lo[1], b0.lo[2], b0.hi[0]};
-        n[1] = f4{b0.hi[1], b0.hi[2], b1.lo[0], b1.lo[1]};
-        n[2] = f4{b1.lo[2], b1.hi[0], b1.hi[1], b1.hi[2]};
+        // boxes are stored as centre + half extent (rounded up so that the stored box contains
+        // the built one): the slab test then needs no per-axis min / max
+        float c0[3], h0[3], c1[3], h1[3];
+        center_half(b0, c0, h0);
+        center_half(b1, c1, h1);
+        n[0] = f4{c0[0], c0[1], c0[2], h0[0]};
+        n[1] = f4{h0[1], h0[2], c1[0], c1[1]};
+        n[2] = f4{c1[2], h1[0], h1[1], h1[2]};
         n[3] = f4{__builtin_bit_cast(float, r0), __builtin_bit_cast(float, r1), 0.0f, 0.0f};
         return node;
     }
