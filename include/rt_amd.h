@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RT_AMD_ABI_VERSION 1
+#define RT_AMD_ABI_VERSION 2
 
 /* ---- error codes ------------------------------------------------------- */
 enum {
@@ -209,6 +209,9 @@ typedef struct rt_render_stats {
      * shading phases / lanes */
     uint64_t sched[6];
     double kernel_ms;      /* HIP-event time of the render kernels of this call */
+    /* wave cycles of the decoupled render kernel (RT_RENDER_COUNTERS, BVH scenes), summed
+     * over waves: whole kernel, shading, starting paths, node steps, leaf tests */
+    uint64_t cycles[6];
 } rt_render_stats;
 
 typedef struct rt_scene_info {

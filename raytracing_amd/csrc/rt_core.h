@@ -59,6 +59,18 @@ RT_HD f3 cross(f3 a, f3 b) {
 RT_HD f3 unit(f3 v) { return v / len(v); }
 RT_HD f3 xyz(f4 v) { return mk(v.x, v.y, v.z); }
 
+// Device code can be compiled without the quad, Perlin-noise and image-texture branches
+// (RT_LEAN: the "lean" render kernels for scenes that have none of them; fewer registers and
+// a shorter shading phase).  Host code always has every feature.
+#if defined(RT_LEAN) && defined(__HIP_DEVICE_COMPILE__)
+#define RT_FEAT_QUAD 0
+#define RT_FEAT_NOISE 0
+#define RT_FEAT_IMAGE 0
+#else
+#define RT_FEAT_QUAD 1
+#define RT_FEAT_NOISE 1
+#define RT_FEAT_IMAGE 1
+#endif
 #define RT_PI 3.1415926535897932385f
 #define RT_INF __builtin_huge_valf()
 
@@ -144,6 +156,7 @@ struct Counters {
     // wave-level schedule of the decoupled kernel: inner-block executions and the lanes
     // active in them, leaf-block executions / lanes, shading phases / lanes
     unsigned long long sched[6];
+    unsigned long long cycles[6]; // wave cycles: whole kernel, shading, starting paths, node steps, leaf tests
 };
 
 template <bool COUNT> struct Cnt {
@@ -356,7 +369,7 @@ RT_HD TraceHit trace_linear(const DevScene &sc, const SceneView &v, const Ray &r
         const f4 *g = v.slots + (size_t)s * stride;
         float t;
         bool h;
-        if (RT_KIND_PRIM(m.x) == RT_PRIM_SPHERE) {
+        if (!RT_FEAT_QUAD || RT_KIND_PRIM(m.x) == RT_PRIM_SPHERE) {
             RT_COUNT(sph);
             h = sphere_test(g[0], g[1], o, d, r.tm, tmin, best.t, t);
             if constexpr (COUNT) cn.sphh += h ? 1 : 0;
@@ -499,7 +512,7 @@ RT_HD void trav_test_leaf(Trav &tv, int leaf_ref, const DevScene &sc, const Scen
                           float tmin, Cnt<COUNT> &cn) {
     int code = ~leaf_ref;
     int s = code >> 1;
-    bool is_quad = (code & 1) != 0;
+    bool is_quad = RT_FEAT_QUAD && (code & 1) != 0;
     const f4 *g = v.slots + (size_t)s * sc.slot_f4;
     float t;
     bool h;
@@ -577,7 +590,7 @@ RT_HD Surf surface_at(const DevScene &sc, const SceneView &vw, const Ray &r, Tra
     f3 outward;
     s.u = 0.0f;
     s.v = 0.0f;
-    if (RT_KIND_PRIM(m.x) == RT_PRIM_SPHERE) {
+    if (!RT_FEAT_QUAD || RT_KIND_PRIM(m.x) == RT_PRIM_SPHERE) {
         f4 g0 = g[0], g1 = g[1];
         f3 center = xyz(g0) + r.tm * xyz(g1);
         outward = (p - center) / g0.w; // sphere.h:68
@@ -653,12 +666,12 @@ RT_HD f3 texture_value(const DevScene &sc, const SceneView &vw, int tex, const S
         t = vw.textures[is_even ? t.even : t.odd];
     }
     if (t.type == RT_TEX_SOLID) return mk(t.color[0], t.color[1], t.color[2]);
-    if (t.type == RT_TEX_NOISE) { // texture.h:85-90
+    if (RT_FEAT_NOISE && t.type == RT_TEX_NOISE) { // texture.h:85-90
         RT_COUNT(noise);
         float ph = t.scale * s.p.z + 10.0f * perlin_turb(sc.perlins[t.perlin], s.p, 7);
         return mk(0.5f, 0.5f, 0.5f) * (1.0f + sinf(ph));
     }
-    if (t.type == RT_TEX_IMAGE) { // texture.h:60-74, rtw_stb_image.h:69-94
+    if (RT_FEAT_IMAGE && t.type == RT_TEX_IMAGE) { // texture.h:60-74, rtw_stb_image.h:69-94
         RT_COUNT(img);
         if (t.image < 0) return mk(0.0f, 0.0f, 1.0f);
         float u = s.u, v = s.v;

@@ -62,7 +62,9 @@ struct rt_scene {
     unsigned long long *d_words = nullptr; // [0] pool counter, [1] ray counter
     rtc::Counters *d_counters = nullptr;
     int n_cu = 256;
+    bool lean = false; // no quads, no noise / image textures: the lean render kernels apply
     LaunchGeom geom; // persistent render kernel: grid, block, LDS bytes, what is staged
+    LaunchGeom pool_geom; // the same for render_pool_bvh (pool_slots = 0: not available)
     // wavefront variant: path-state arrays and queues (allocated on first use)
     void *wf_mem = nullptr;
     unsigned wf_slots = 0;
@@ -164,7 +166,8 @@ LaunchGeom choose_geom(rt_scene *s, uint32_t flags) {
     const bool short_ok = dv.n_nodes < 32768 && dv.n_slots < 16384; // 16-bit stack entries
     lg.block = block;
     lg.lds_scene = false;
-    dv.lds_records = 0;
+    lg.lds_records = 0;
+    lg.pool_slots = 0;
     int bpc = bpc_target;
     if (!(flags & RT_SCENE_FORCE_GLOBAL) && short_ok) {
         for (bpc = bpc_target; bpc >= 1 && !lg.lds_scene; bpc--) {
@@ -172,7 +175,7 @@ LaunchGeom choose_geom(rt_scene *s, uint32_t flags) {
             size_t stack = bvh ? (size_t)levels * block * sizeof(short) : 0;
             if (all_bytes + stack <= budget) {
                 lg.lds_scene = true;
-                dv.lds_records = 1;
+                lg.lds_records = 1;
                 lg.lds_bytes = (int)(all_bytes + stack);
             } else if (geom_bytes + stack <= budget) {
                 lg.lds_scene = true;
@@ -188,6 +191,48 @@ LaunchGeom choose_geom(rt_scene *s, uint32_t flags) {
     }
     lg.lds_bytes = std::max(lg.lds_bytes, 16);
     lg.grid = s->n_cu * std::max(bpc, 1);
+    return lg;
+}
+
+// Launch shape of render_pool_bvh: one workgroup of RT_POOL_MAX_THREADS lanes per CU; LDS
+// holds the scene (if it fits), every wave's path slots and lists, and the traversal stacks.
+// pool_slots = 0 in the result: the kernel cannot run for this scene (linear scan).
+LaunchGeom choose_pool_geom(rt_scene *s, uint32_t flags) {
+    LaunchGeom lg;
+    const rtc::DevScene &dv = s->dev;
+    lg.block = std::max(64, std::min(RT_POOL_MAX_THREADS, env_int("RT_AMD_POOL_BLOCK", RT_POOL_MAX_THREADS) / 64 * 64));
+    lg.grid = s->n_cu;
+    lg.lds_scene = false;
+    lg.lds_records = 0;
+    lg.lds_bytes = 16;
+    lg.pool_slots = 0;
+    if (dv.traversal != rtc::TRAV_BVH) return lg;
+    const int n_waves = lg.block / 64;
+    const int levels = s->info.bvh_depth + 1;
+    const size_t geom_bytes = ((size_t)dv.n_slots * dv.slot_f4 + (size_t)dv.n_nodes * 4) * sizeof(f4);
+    const size_t all_bytes = scene_lds_bytes(dv);
+    const bool short_ok = dv.n_nodes < 32768 && dv.n_slots < 16384;
+    const int want = std::max(64, std::min(1024, env_int("RT_AMD_POOL_SLOTS", 128) / 32 * 32));
+    for (int m = want; m >= 64 && lg.pool_slots == 0; m -= 32) {
+        const size_t pools = (size_t)n_waves * m * (RT_POOL_SLOT_F4 * sizeof(f4) + 2 * sizeof(unsigned short));
+        const size_t stack16 = (size_t)levels * lg.block * sizeof(short);
+        const size_t stack32 = (size_t)levels * lg.block * sizeof(int);
+        if (!(flags & RT_SCENE_FORCE_GLOBAL) && short_ok && all_bytes + pools + stack16 <= (size_t)kMaxLdsBytes) {
+            lg.lds_scene = true;
+            lg.lds_records = 1;
+            lg.lds_bytes = (int)(all_bytes + pools + stack16);
+            lg.pool_slots = m;
+        } else if (!(flags & RT_SCENE_FORCE_GLOBAL) && short_ok && m == want &&
+                   geom_bytes + pools + stack16 <= (size_t)kMaxLdsBytes) {
+            lg.lds_scene = true;
+            lg.lds_bytes = (int)(geom_bytes + pools + stack16);
+            lg.pool_slots = m;
+        } else if (((flags & RT_SCENE_FORCE_GLOBAL) || !short_ok || geom_bytes > (size_t)kMaxLdsBytes / 2) &&
+                   pools + stack32 <= (size_t)kMaxLdsBytes) {
+            lg.lds_bytes = (int)(pools + stack32);
+            lg.pool_slots = m;
+        }
+    }
     return lg;
 }
 
@@ -262,6 +307,9 @@ int rt_scene_create(const rt_scene_desc *d, int device, uint32_t flags, rt_scene
     s->info.n_prims = n;
     s->info.n_spheres = hs.n_spheres;
     s->info.n_quads = hs.n_quads;
+    s->lean = hs.n_quads == 0 && !env_int("RT_AMD_NO_LEAN", 0);
+    for (const rt_texture &t : hs.textures) // the table holds only what a material can reach
+        if (t.type == RT_TEX_NOISE || t.type == RT_TEX_IMAGE) s->lean = false;
     s->info.n_nodes = hs.n_nodes;
     s->info.bvh_depth = hs.bvh_depth;
 
@@ -303,18 +351,27 @@ int rt_scene_create(const rt_scene_desc *d, int device, uint32_t flags, rt_scene
     dv.traversal = linear ? rtc::TRAV_LINEAR : rtc::TRAV_BVH;
     dv.n_chains = d->n_chains;
     dv.n_xf_ops = (int)(xf_packed.size() / 3);
+    dv.lds_records = 0; // set per launch from the launch geometry
 
     int n_cu = 0;
     if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n_cu > 0)
         s->n_cu = n_cu;
     hipError_t e = rtl::set_mega_lds_limit(kMaxLdsBytes);
+    if (e == hipSuccess) e = rtl::set_mega_lds_limit_lean(kMaxLdsBytes);
     if (e == hipSuccess) e = rtl::set_wavefront_lds_limit(kMaxLdsBytes);
+    if (e == hipSuccess) e = rtl::set_pool_lds_limit(kMaxLdsBytes);
     if (e != hipSuccess) {
         rt_scene_destroy(s);
         return fail(RT_ERR_HIP, "cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
     }
 
     s->geom = choose_geom(s, flags);
+    s->pool_geom = choose_pool_geom(s, flags);
+    if (env_int("RT_AMD_DEBUG", 0))
+        fprintf(stderr, "librt_amd: render geometry grid %d block %d lds %d (scene %d records %d), resident blocks/CU %d; pool: block %d lds %d slots %d\n",
+                s->geom.grid, s->geom.block, s->geom.lds_bytes, (int)s->geom.lds_scene, s->geom.lds_records,
+                rtl::mega_blocks_per_cu(s->geom.block, s->geom.lds_bytes, s->geom.lds_scene), s->pool_geom.block,
+                s->pool_geom.lds_bytes, s->pool_geom.pool_slots);
     s->info.lds_resident = s->geom.lds_scene ? 1 : 0;
     *out = s;
     return RT_OK;
@@ -412,7 +469,12 @@ int rt_render_device(rt_scene *s, const rt_camera_desc *cam, const rt_render_opt
     }
 
     const bool count = (opts->flags & RT_RENDER_COUNTERS) != 0 && stats != nullptr;
-    const LaunchGeom lg = s->geom;
+    // BVH scenes: 1 = decoupled (default), 0 = whole ray, 2 = path pool in LDS (experimental)
+    int scheduler = env_int("RT_AMD_SCHEDULER", 1);
+    if (scheduler == 2 && (s->pool_geom.pool_slots == 0 || wavefront)) scheduler = 1;
+    const LaunchGeom lg = scheduler == 2 ? s->pool_geom : s->geom;
+    rtc::DevScene dev = s->dev;
+    dev.lds_records = lg.lds_records;
     unsigned wf_slots = 0;
     int wf_rounds = 0;
     if (wavefront) {
@@ -445,7 +507,9 @@ int rt_render_device(rt_scene *s, const rt_camera_desc *cam, const rt_render_opt
         rp.stage = s->stage;
         rp.next_chunk = reinterpret_cast<unsigned *>(s->d_words);
         rp.counters = count ? s->d_counters : nullptr;
-        rp.scheduler = env_int("RT_AMD_SCHEDULER", 1);
+        rp.scheduler = scheduler;
+        rp.pool_slots = lg.pool_slots;
+        rp.dispatch_min = std::max(1, std::min(64, env_int("RT_AMD_DISPATCH_MIN", 8)));
         rp.min_ready = std::max(1, std::min(64, env_int("RT_AMD_MIN_READY", 40)));
         rp.leaf_min = std::max(1, std::min(64, env_int("RT_AMD_LEAF_MIN", 24)));
         rp.blocked_min = std::max(1, std::min(64, env_int("RT_AMD_BLOCKED_MIN", 8)));
@@ -459,12 +523,17 @@ int rt_render_device(rt_scene *s, const rt_camera_desc *cam, const rt_render_opt
         }
         if (stats) RT_HIP(hipEventRecord(ev0, stream));
         if (!wavefront) {
-            RT_HIP(rtl::launch_mega(s->dev, dc, rp, lg, stream));
+            if (scheduler == 2)
+                RT_HIP(rtl::launch_pool(dev, dc, rp, lg, stream));
+            else if (s->lean)
+                RT_HIP(rtl::launch_mega_lean(dev, dc, rp, lg, stream));
+            else
+                RT_HIP(rtl::launch_mega(dev, dc, rp, lg, stream));
         } else if (dc.max_depth <= 0) { // camera.h:141: every path is black
             RT_HIP(hipMemsetAsync(s->stage, 0, per_sample * sc_n, stream));
         } else {
             int rounds = 0;
-            RT_HIP(rtl::render_wavefront(s->dev, dc, rp, s->wf, wf_slots, lg, s->wf_host_cnt, stream, &rounds));
+            RT_HIP(rtl::render_wavefront(dev, dc, rp, s->wf, wf_slots, lg, s->wf_host_cnt, stream, &rounds));
             wf_rounds += rounds;
         }
         if (stats) RT_HIP(hipEventRecord(ev1, stream));
@@ -503,6 +572,7 @@ int rt_render_device(rt_scene *s, const rt_camera_desc *cam, const rt_render_opt
             stats->image_evals = c.image_evals;
             stats->checker_evals = c.checker_evals;
             for (int k = 0; k < 6; k++) stats->sched[k] = c.sched[k];
+            for (int k = 0; k < 6; k++) stats->cycles[k] = c.cycles[k];
         }
     }
     return RT_OK;

@@ -20,95 +20,23 @@
 #include "rt_core.h"
 #include "rt_launch.h"
 #include "rt_stage.h"
+#include "rt_wavepool.h"
 
 using namespace rtc;
+
+// This file is compiled twice: as is, and with -DRT_LEAN (render kernels only, without the
+// quad / noise / image branches; launchers suffixed _lean).
+#ifdef RT_LEAN
+#define RT_LAUNCH_NAME(x) x##_lean
+#else
+#define RT_LAUNCH_NAME(x) x
+#endif
 
 #ifndef RT_INNER_UNROLL
 #define RT_INNER_UNROLL 4
 #endif
 
 namespace {
-
-__device__ __forceinline__ unsigned wave_bcast32(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
-
-template <bool COUNT> __device__ __forceinline__ void flush_counters(Counters *out, const Cnt<COUNT> &cn) {
-    if constexpr (COUNT) {
-        atomicAdd(&out->box_tests, (unsigned long long)cn.box);
-        atomicAdd(&out->sphere_tests, (unsigned long long)cn.sph);
-        atomicAdd(&out->sphere_hits, (unsigned long long)cn.sphh);
-        atomicAdd(&out->quad_tests, (unsigned long long)cn.quad);
-        atomicAdd(&out->shades[0], (unsigned long long)cn.sh0);
-        atomicAdd(&out->shades[1], (unsigned long long)cn.sh1);
-        atomicAdd(&out->shades[2], (unsigned long long)cn.sh2);
-        atomicAdd(&out->shades[3], (unsigned long long)cn.sh3);
-        atomicAdd(&out->noise_evals, (unsigned long long)cn.noise);
-        atomicAdd(&out->image_evals, (unsigned long long)cn.img);
-        atomicAdd(&out->checker_evals, (unsigned long long)cn.chk);
-    }
-}
-
-// Per-wave pool of paths.  The global counter hands out chunks of 64 pixels x
-// RT_POOL_SAMPLES samples; everything per chunk is wave-uniform.
-struct WavePool {
-    unsigned k, k_end;      // next / end path within the current chunk (k_end = 0: no chunk)
-    unsigned strip, s_base; // first pixel = strip * 64, first local sample of the chunk
-    unsigned x0, y0;        // pixel coordinates of the strip's first pixel
-    bool exhausted;
-};
-
-__device__ __forceinline__ void pool_init(WavePool &wp) {
-    wp.k = wp.k_end = 0;
-    wp.strip = wp.s_base = wp.x0 = wp.y0 = 0;
-    wp.exhausted = false;
-}
-
-// Makes sure the wave holds a chunk with paths left, if any remain.  Wave-uniform.
-__device__ __forceinline__ void pool_refill(WavePool &wp, const RenderParams &rp, int lane) {
-    if (wp.k < wp.k_end || wp.exhausted) return;
-    unsigned chunk = 0;
-    if (lane == 0) chunk = atomicAdd(rp.next_chunk, 1u);
-    chunk = wave_bcast32(chunk);
-    if (chunk >= rp.n_chunks) {
-        wp.exhausted = true;
-        return;
-    }
-    unsigned strip = chunk / rp.n_sample_groups;
-    unsigned sg = chunk - strip * rp.n_sample_groups;
-    wp.strip = strip;
-    wp.s_base = sg * RT_POOL_SAMPLES;
-    unsigned left = (unsigned)rp.sample_count - wp.s_base;
-    wp.k = 0;
-    wp.k_end = 64u * (left < RT_POOL_SAMPLES ? left : RT_POOL_SAMPLES);
-    unsigned first = strip * 64u;
-    wp.y0 = first / (unsigned)rp.width;
-    wp.x0 = first - wp.y0 * (unsigned)rp.width;
-}
-
-// Decodes path index `k` of the current chunk; false if it falls outside the image.
-__device__ __forceinline__ bool pool_decode(const WavePool &wp, const RenderParams &rp, unsigned k,
-                                            unsigned &pixel, unsigned &s_local, int &px, int &py) {
-    unsigned j = k & 63u;
-    s_local = wp.s_base + (k >> 6);
-    pixel = wp.strip * 64u + j;
-    unsigned x = wp.x0 + j, y = wp.y0;
-    while (x >= (unsigned)rp.width) {
-        x -= (unsigned)rp.width;
-        y++;
-    }
-    px = (int)x;
-    py = (int)y;
-    return pixel < (unsigned)rp.n_pixels;
-}
-
-__device__ __forceinline__ void write_record(const RenderParams &rp, unsigned s_local, unsigned pixel, f3 L,
-                                             unsigned n_rays) {
-    f4 rec;
-    rec.x = L.x;
-    rec.y = L.y;
-    rec.z = L.z;
-    rec.w = __builtin_bit_cast(float, n_rays);
-    rp.stage[(size_t)s_local * (size_t)rp.n_pixels + pixel] = rec;
-}
 
 // ------------------------------------------------------------------------------------------
 // One whole ray per lane per iteration.  Linear scenes: every lane walks the same
@@ -244,6 +172,10 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
     Cnt<COUNT> cn;
     // wave-level schedule statistics (instrumented variant only), kept by lane 0
     unsigned long long w_t_iters = 0, w_t_lanes = 0, w_l_iters = 0, w_l_lanes = 0, w_s_phases = 0, w_s_lanes = 0;
+    long long c_shade = 0, c_regen = 0, c_inner = 0, c_leaf = 0, c_mark = 0;
+    const long long c_begin = COUNT ? clock64() : 0;
+#define RT_TICK() if constexpr (COUNT) c_mark = clock64()
+#define RT_TOCK(acc) if constexpr (COUNT) acc += clock64() - c_mark
 
     for (;;) {
         if constexpr (COUNT) {
@@ -254,6 +186,7 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
             }
         }
         // ---- shade the lanes whose closest hit is known ---------------------------------------
+        RT_TICK();
         if (state == ST_READY) {
             TraceHit h;
             h.t = tv.best_t;
@@ -268,6 +201,8 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
                 state = ST_IDLE;
             }
         }
+        RT_TOCK(c_shade);
+        RT_TICK();
         // ---- hand new paths to idle lanes -------------------------------------------------------
         unsigned long long need = __ballot(state == ST_IDLE);
         // starting paths (camera ray, sampler seed) is batched like everything else: wait
@@ -296,6 +231,7 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
                 wp.k = wp.k + n_need < wp.k_end ? wp.k + n_need : wp.k_end;
             }
         }
+        RT_TOCK(c_regen);
         const bool pool_dry = wp.exhausted && wp.k >= wp.k_end;
         if (!__any(state != ST_IDLE)) {
             if (pool_dry) break;
@@ -315,6 +251,7 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
                 }
             }
             const bool trav = state == ST_TRAV;
+            RT_TICK();
             // RT_INNER_UNROLL node steps per scheduling decision: the ballots / thresholds
             // below cost about as much as a node step, so they are amortised.
 #pragma unroll
@@ -327,6 +264,8 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
                     trav_pop(tv, stack, stack_stride);
                 }
             }
+            RT_TOCK(c_inner);
+            RT_TICK();
             const bool blocked = trav && tv.ref < 0 && tv.ref != RT_TRAV_DONE; // second leaf, slot taken
             const bool has_pend = trav && pend != 0;
             unsigned long long pmask = __ballot(has_pend);
@@ -348,6 +287,7 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
                     }
                 }
             }
+            RT_TOCK(c_leaf);
             if (trav && tv.ref == RT_TRAV_DONE && pend == 0) state = ST_READY;
         }
     }
@@ -360,10 +300,19 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
             atomicAdd(&rp.counters->sched[3], w_l_lanes);
             atomicAdd(&rp.counters->sched[4], w_s_phases);
             atomicAdd(&rp.counters->sched[5], w_s_lanes);
+            atomicAdd(&rp.counters->cycles[0], (unsigned long long)(clock64() - c_begin));
+            atomicAdd(&rp.counters->cycles[1], (unsigned long long)c_shade);
+            atomicAdd(&rp.counters->cycles[2], (unsigned long long)c_regen);
+            atomicAdd(&rp.counters->cycles[3], (unsigned long long)c_inner);
+            atomicAdd(&rp.counters->cycles[4], (unsigned long long)c_leaf);
         }
     }
 }
 
+#undef RT_TICK
+#undef RT_TOCK
+
+#ifndef RT_LEAN
 // accum[pixel] += sum over the launch's samples, in sample order; ray counts are
 // summed per workgroup and added to *ray_count.
 __global__ void __launch_bounds__(256) reduce_stage(const f4 *stage, int n_pixels, int sample_count,
@@ -439,6 +388,8 @@ trace_batch(DevScene sc, const rt_ray *rays, long long n_rays, float tmin, float
     }
 }
 
+#endif // !RT_LEAN
+
 } // namespace
 
 // ------------------------------------------------------------------------------------------
@@ -469,7 +420,7 @@ static hipError_t launch_mega_bvh_tc(const DevScene &sc, const DevCamera &cam, c
     return hipGetLastError();
 }
 
-hipError_t launch_mega(const DevScene &sc, const DevCamera &cam, const RenderParams &rp, const LaunchGeom &lg,
+hipError_t RT_LAUNCH_NAME(launch_mega)(const DevScene &sc, const DevCamera &cam, const RenderParams &rp, const LaunchGeom &lg,
                        hipStream_t stream) {
     if (sc.traversal == TRAV_LINEAR)
         return lg.lds_scene ? launch_mega_tc<TRAV_LINEAR, true>(sc, cam, rp, lg, stream)
@@ -481,9 +432,19 @@ hipError_t launch_mega(const DevScene &sc, const DevCamera &cam, const RenderPar
                         : launch_mega_bvh_tc<false>(sc, cam, rp, lg, stream);
 }
 
+#ifndef RT_LEAN
 int mega_waves_per_simd() { return RT_MEGA_WAVES_PER_SIMD; }
 
-hipError_t set_mega_lds_limit(int bytes) {
+// Workgroups of the decoupled render kernel the runtime will keep resident per CU.
+int mega_blocks_per_cu(int block, int lds_bytes, bool lds_scene) {
+    int n = 0;
+    hipError_t e = lds_scene ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_mega_bvh<true, false>, block, lds_bytes)
+                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_mega_bvh<false, false>, block, lds_bytes);
+    return e == hipSuccess ? n : -1;
+}
+#endif // !RT_LEAN
+
+hipError_t RT_LAUNCH_NAME(set_mega_lds_limit)(int bytes) {
     hipError_t e = hipSuccess;
 #define RT_SET(TR, L, C)                                                                                     \
     if (e == hipSuccess)                                                                                     \
@@ -510,6 +471,7 @@ hipError_t set_mega_lds_limit(int bytes) {
     return e;
 }
 
+#ifndef RT_LEAN
 hipError_t launch_reduce(const f4 *stage, int n_pixels, int sample_count, float *accum,
                          unsigned long long *ray_count, hipStream_t stream) {
     int grid = (n_pixels + 255) / 256;
@@ -530,5 +492,6 @@ hipError_t launch_trace(const DevScene &sc, const rt_ray *rays, long long n, flo
                            tmin, tmax, hits);
     return hipGetLastError();
 }
+#endif // !RT_LEAN
 
 } // namespace rtl

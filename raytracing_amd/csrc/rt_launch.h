@@ -10,6 +10,9 @@
 #define RT_MEGA_WAVES_PER_SIMD 4
 #endif
 #define RT_TRACE_THREADS 256
+#define RT_POOL_MAX_THREADS 512  // render_pool_bvh: 2 waves per SIMD, up to 256 VGPRs
+#define RT_POOL_WAVES_PER_SIMD 2
+#define RT_POOL_SLOT_F4 5        // 80-byte path slots of render_pool_bvh
 #define RT_POOL_SAMPLES 4u // a wave reserves 64 pixels x this many samples from the global counter
 
 struct RenderParams {
@@ -27,12 +30,16 @@ struct RenderParams {
     int leaf_min;  // decoupled: lanes that must hold a parked leaf before the leaf block runs
     int blocked_min; // decoupled: ... or this many lanes stalled on a second leaf
     int regen_min;   // decoupled: idle lanes that must accumulate before new paths are started
+    int pool_slots;   // path pool: path slots per wave (LDS)
+    int dispatch_min; // path pool: idle engines that must accumulate before pending rays are handed out
 };
 
 struct LaunchGeom {
     int grid, block;
     int lds_bytes;
-    bool lds_scene;
+    bool lds_scene;  // slots + nodes are staged into LDS
+    int lds_records; // ... and so are the per-slot records and the texture table
+    int pool_slots;  // render_pool_bvh: path slots per wave (0: this geometry is not for it)
 };
 
 // Path state of the wavefront variant: structure-of-arrays over the in-flight path slots.
@@ -56,7 +63,15 @@ hipError_t render_wavefront(const rtc::DevScene &sc, const rtc::DevCamera &cam, 
 hipError_t launch_mega(const rtc::DevScene &sc, const rtc::DevCamera &cam, const RenderParams &rp,
                        const LaunchGeom &lg, hipStream_t stream);
 hipError_t set_mega_lds_limit(int bytes);
+// the same kernels compiled without the quad / noise / image branches (rt_scene::lean)
+hipError_t launch_mega_lean(const rtc::DevScene &sc, const rtc::DevCamera &cam, const RenderParams &rp,
+                            const LaunchGeom &lg, hipStream_t stream);
+hipError_t set_mega_lds_limit_lean(int bytes);
+hipError_t launch_pool(const rtc::DevScene &sc, const rtc::DevCamera &cam, const RenderParams &rp,
+                       const LaunchGeom &lg, hipStream_t stream);
+hipError_t set_pool_lds_limit(int bytes);
 int mega_waves_per_simd(); // register budget the render kernels were compiled for
+int mega_blocks_per_cu(int block, int lds_bytes, bool lds_scene);
 hipError_t launch_reduce(const rtc::f4 *stage, int n_pixels, int sample_count, float *accum,
                          unsigned long long *ray_count, hipStream_t stream);
 hipError_t launch_trace(const rtc::DevScene &sc, const rt_ray *rays, long long n, float tmin, float tmax,
