@@ -197,7 +197,7 @@ def main():
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS,
                          "traffic": measured_traffic(args.scene, W, H, args.spp), "traffic_unit": "bytes/launch",
-                         "kernel": "render_mega", "kernel_ms_avg": avg_kernel_s * 1e3,
+                         "kernel": "render_mega_bvh" if info.n_nodes else "render_mega", "kernel_ms_avg": avg_kernel_s * 1e3,
                          "launches": n_launches, "algorithmic_flops_per_launch": alg_flops / launches_per_step,
                          "counts_per_launch": {"paths": st.paths, "rays": st.rays, "box_tests": st.box_tests,
                                                "sphere_tests": st.sphere_tests, "sphere_hits": st.sphere_hits,
