@@ -647,6 +647,21 @@ int main(int argc, char **argv) {
     }
     g_mode = g_args[0];
     const std::string &s = g_args[1];
+    if (g_mode == "image") { // rt_ref image <file> <out.rtimg>: the texels rtw_image (stb_image) produces
+        if (g_args.size() < 3) return 2;
+        rtw_image im;
+        if (!im.load(s)) {
+            fprintf(stderr, "harness: cannot load %s\n", s.c_str());
+            return 1;
+        }
+        FILE *f = fopen(g_args[2].c_str(), "wb");
+        if (!f) return 1;
+        fprintf(f, "RTIMG1\n%d %d\n", im.image_width, im.image_height);
+        fwrite(im.bdata, 1, (size_t)im.image_width * im.image_height * 3, f);
+        fclose(f);
+        printf("{\"width\": %d, \"height\": %d}\n", im.image_width, im.image_height);
+        return 0;
+    }
     if (s == "bouncing_spheres") bouncing_spheres();
     else if (s == "checkered_spheres") checkered_spheres();
     else if (s == "earth") earth();

@@ -10,6 +10,7 @@
 // Header-only and multi-TU safe (everything inline).
 #pragma once
 
+#include "rtamd_jpeg.hpp"
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -435,27 +436,61 @@ class rtw_image {
         size_t dot = n.find_last_of('.');
         return (dot == std::string::npos ? n : n.substr(0, dot)) + ext;
     }
+    // stb_image's float decode followed by rtw_stb_image.h:96-118: byte -> pow(b/255, 2.2)
+    // (double pow of float arguments, rounded to float) -> byte
+    static uint8_t linear_byte(uint8_t b) {
+        float v = (float)pow((double)(b / 255.0f), (double)2.2f);
+        return v <= 0.0 ? 0 : (1.0 <= v ? 255 : (uint8_t)(256.0 * v));
+    }
     bool load_one(const std::string &name) {
         FILE *f = fopen(name.c_str(), "rb");
         if (!f) return false;
-        char magic[8] = {0};
-        int ww = 0, hh = 0, maxv = 255;
+        std::vector<uint8_t> file;
+        uint8_t chunk[65536];
+        size_t got;
+        while ((got = fread(chunk, 1, sizeof(chunk), f)) > 0) file.insert(file.end(), chunk, chunk + got);
+        fclose(f);
         bool ok = false;
-        if (fscanf(f, "%7s", magic) == 1) {
-            if (!strcmp(magic, "RTIMG1") && fscanf(f, "%d %d", &ww, &hh) == 2 && fgetc(f) == '\n') {
-                data.resize((size_t)ww * hh * 3);
-                ok = ww > 0 && hh > 0 && fread(data.data(), 1, data.size(), f) == data.size();
-            } else if (!strcmp(magic, "P6") && fscanf(f, "%d %d %d", &ww, &hh, &maxv) == 3 && maxv == 255 &&
-                       isspace(fgetc(f))) {
-                data.resize((size_t)ww * hh * 3);
-                ok = ww > 0 && hh > 0 && fread(data.data(), 1, data.size(), f) == data.size();
-                for (uint8_t &b : data) {
-                    float v = powf(b / 255.0f, 2.2f);
-                    b = v <= 0.0 ? 0 : (1.0 <= v ? 255 : (uint8_t)(256.0 * v));
+        int ww = 0, hh = 0;
+        data.clear();
+        if (file.size() > 3 && file[0] == 0xff && file[1] == 0xd8) { // JPEG, as the reference's earthmap.jpg
+            rtamd::jpeg::Image im;
+            std::string why;
+            if (rtamd::jpeg::decode(file.data(), file.size(), im, &why)) {
+                ww = im.width;
+                hh = im.height;
+                data.resize(im.rgb.size());
+                uint8_t lut[256];
+                for (int i = 0; i < 256; i++) lut[i] = linear_byte((uint8_t)i);
+                for (size_t i = 0; i < data.size(); i++) data[i] = lut[im.rgb[i]];
+                ok = true;
+            } else {
+                std::cerr << "ERROR: " << name << ": " << why << "\n";
+            }
+        } else {
+            // text header, then raw bytes: "RTIMG1\nW H\n" (texels already linear) or binary PPM
+            size_t pos = 0;
+            auto token = [&]() {
+                while (pos < file.size() && isspace(file[pos])) pos++;
+                std::string t;
+                while (pos < file.size() && !isspace(file[pos])) t.push_back((char)file[pos++]);
+                return t;
+            };
+            std::string magic = token();
+            if (magic == "RTIMG1" || magic == "P6") {
+                ww = atoi(token().c_str());
+                hh = atoi(token().c_str());
+                int maxv = magic == "P6" ? atoi(token().c_str()) : 255;
+                pos++; // the single whitespace byte that ends the header
+                size_t need = (size_t)(ww > 0 ? ww : 0) * (size_t)(hh > 0 ? hh : 0) * 3;
+                if (ww > 0 && hh > 0 && maxv == 255 && pos + need <= file.size()) {
+                    data.assign(file.begin() + (long)pos, file.begin() + (long)(pos + need));
+                    if (magic == "P6")
+                        for (uint8_t &b : data) b = linear_byte(b);
+                    ok = true;
                 }
             }
         }
-        fclose(f);
         if (!ok) data.clear();
         w = ww;
         h = hh;

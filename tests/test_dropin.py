@@ -39,13 +39,47 @@ def test_scene_programs_flatten_like_the_reference(scene, tmp_path):
     _ensure_built()
     env = dict(os.environ)
     gold = abi.SceneArrays.load(os.path.join(GOLDEN, scene + ".rtscene"))
-    if scene == "earth":  # the texel buffer is input data: hand it over in the raw .rtimg form
-        _write_rtimg(str(tmp_path / "earthmap.rtimg"), gold)
-        env["RTW_IMAGES"] = str(tmp_path)
+    if scene == "earth":  # the reference's texture file, decoded by the drop-in's own JPEG decoder
+        env["RTW_IMAGES"] = os.path.join(GOLDEN, "images")
     out = str(tmp_path / "dump.rtscene")
     subprocess.run([RT_SCENES, scene, "--dump", out], check=True, env=env, capture_output=True)
     assert open(out, "rb").read() == open(os.path.join(GOLDEN, scene + ".rtscene"), "rb").read()
     assert open(out + ".cam", "rb").read() == open(os.path.join(GOLDEN, scene + ".cam"), "rb").read()
+
+
+def test_raw_texel_dump_is_accepted_too(tmp_path):
+    """A texture may also be handed over as a raw dump of linear texels (<name>.rtimg)."""
+    _ensure_built()
+    gold = abi.SceneArrays.load(os.path.join(GOLDEN, "earth.rtscene"))
+    _write_rtimg(str(tmp_path / "earthmap.rtimg"), gold)
+    out = str(tmp_path / "dump.rtscene")
+    subprocess.run([RT_SCENES, "earth", "--dump", out], check=True, env=dict(os.environ, RTW_IMAGES=str(tmp_path)),
+                   capture_output=True)
+    assert open(out, "rb").read() == open(os.path.join(GOLDEN, "earth.rtscene"), "rb").read()
+
+
+JPEG_DIR = os.path.join(GOLDEN, "jpeg")
+JPEG_CASES = sorted(f[:-4] for f in os.listdir(JPEG_DIR) if f.endswith(".jpg") and f != "progressive.jpg")
+
+
+@pytest.mark.parametrize("name", JPEG_CASES)
+def test_jpeg_decoder_matches_the_reference_texels(name, tmp_path):
+    """tests/golden/jpeg/<name>.rtimg holds what the unmodified reference (rtw_image over
+    stb_image) makes of <name>.jpg (oracle/make_jpeg_fixtures.py): sampling 4:4:4 / 4:2:2 /
+    4:2:0, grayscale, restart intervals, odd sizes.  The drop-in's decoder must give the same
+    bytes.  (Vertical-only subsampling is not covered: Pillow cannot write it.)"""
+    _ensure_built()
+    out = str(tmp_path / "out.rtimg")
+    subprocess.run([os.path.join(BIN, "rt_image"), os.path.join(JPEG_DIR, name + ".jpg"), out], check=True,
+                   capture_output=True)
+    assert open(out, "rb").read() == open(os.path.join(JPEG_DIR, name + ".rtimg"), "rb").read()
+
+
+def test_progressive_jpeg_is_refused_loudly(tmp_path):
+    _ensure_built()
+    r = subprocess.run([os.path.join(BIN, "rt_image"), os.path.join(JPEG_DIR, "progressive.jpg"),
+                        str(tmp_path / "o.rtimg")], capture_output=True)
+    assert r.returncode != 0 and b"progressive" in r.stderr
 
 
 def test_missing_image_is_not_fatal(tmp_path):
