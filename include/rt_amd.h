@@ -235,8 +235,8 @@ int rt_device_count(void);
 /* camera::initialize (camera.h:76-111), same fp32 arithmetic. Host only. */
 int rt_camera_initialize(const rt_camera_desc *cam, rt_camera_frame *out);
 
-/* Replaces the scene half of camera::render's prologue: bakes instance
- * wrappers (hittable.h:51-344) into world-space quads, derives the quad
+/* Replaces the scene half of camera::render's prologue: packs the instance
+ * wrappers (hittable.h:51-344) for use at intersection time, derives the quad
  * constants (quad.h:15-20), builds the traversal structure that stands in for
  * bvh_node (bvh.h:48-75) / hittable_list (hittable_list.h:29-43) and copies
  * everything to `device`.  The descriptor may be freed afterwards. */

@@ -59,17 +59,19 @@ RT_HD f3 cross(f3 a, f3 b) {
 RT_HD f3 unit(f3 v) { return v / len(v); }
 RT_HD f3 xyz(f4 v) { return mk(v.x, v.y, v.z); }
 
-// Device code can be compiled without the quad, Perlin-noise and image-texture branches
-// (RT_LEAN: the "lean" render kernels for scenes that have none of them; fewer registers and
+// Device code can be compiled without the quad, Perlin-noise, image-texture and instance-wrapper
+// branches (RT_LEAN: the "lean" render kernels for scenes that have none of them; fewer registers and
 // a shorter shading phase).  Host code always has every feature.
 #if defined(RT_LEAN) && defined(__HIP_DEVICE_COMPILE__)
 #define RT_FEAT_QUAD 0
 #define RT_FEAT_NOISE 0
 #define RT_FEAT_IMAGE 0
+#define RT_FEAT_CHAIN 0
 #else
 #define RT_FEAT_QUAD 1
 #define RT_FEAT_NOISE 1
 #define RT_FEAT_IMAGE 1
+#define RT_FEAT_CHAIN 1
 #endif
 #define RT_PI 3.1415926535897932385f
 #define RT_INF __builtin_huge_valf()
@@ -364,7 +366,7 @@ RT_HD TraceHit trace_linear(const DevScene &sc, const SceneView &v, const Ray &r
             cur_chain = m.z;
             o = r.o;
             d = r.d;
-            if (cur_chain >= 0) chain_ray_to_object(sc, cur_chain, o, d);
+            if (RT_FEAT_CHAIN && cur_chain >= 0) chain_ray_to_object(sc, cur_chain, o, d);
         }
         const f4 *g = v.slots + (size_t)s * stride;
         float t;
@@ -516,15 +518,22 @@ RT_HD void trav_test_leaf(Trav &tv, int leaf_ref, const DevScene &sc, const Scen
     const f4 *g = v.slots + (size_t)s * sc.slot_f4;
     float t;
     bool h;
+    // a primitive inside instance wrappers is tested in its object space (t is the same
+    // parameter there: the direction is transformed, not normalised)
+    f3 o = r.o, d = r.d;
+    if (RT_FEAT_CHAIN && sc.n_chains > 0) {
+        int chain = v.rec_i[s].z;
+        if (chain >= 0) chain_ray_to_object(sc, chain, o, d);
+    }
     // candidates at t == best_t are admitted here and sorted out by the tie rule
     if (!is_quad) {
         RT_COUNT(sph);
-        h = sphere_test(g[0], g[1], r.o, r.d, r.tm, tmin, RT_INF, t);
+        h = sphere_test(g[0], g[1], o, d, r.tm, tmin, RT_INF, t);
         if constexpr (COUNT) cn.sphh += h ? 1 : 0;
         h = h && t <= tv.best_t;
     } else {
         RT_COUNT(quad);
-        h = quad_test(g[0], g[1], g[2], g[3], r.o, r.d, tmin, tv.best_t, t);
+        h = quad_test(g[0], g[1], g[2], g[3], o, d, tmin, tv.best_t, t);
     }
     if (h) {
         bool take = t < tv.best_t;
@@ -584,7 +593,7 @@ RT_HD Surf surface_at(const DevScene &sc, const SceneView &vw, const Ray &r, Tra
     i4 m = vw.rec_i[h.slot];
     s.rec = m;
     f3 o = r.o, d = r.d;
-    if (m.z >= 0) chain_ray_to_object(sc, m.z, o, d);
+    if (RT_FEAT_CHAIN && m.z >= 0) chain_ray_to_object(sc, m.z, o, d);
     const f4 *g = vw.slots + (size_t)h.slot * sc.slot_f4;
     f3 p = o + h.t * d; // ray.h:20
     f3 outward;
@@ -607,7 +616,7 @@ RT_HD Surf surface_at(const DevScene &sc, const SceneView &vw, const Ray &r, Tra
     s.outward = outward;
     s.front = dot(d, outward) < 0; // hittable.h:20-25
     f3 n = s.front ? outward : -outward;
-    if (m.z >= 0) chain_hit_to_world(sc, m.z, p, n);
+    if (RT_FEAT_CHAIN && m.z >= 0) chain_hit_to_world(sc, m.z, p, n);
     s.p = p;
     s.n = n;
     return s;

@@ -308,6 +308,7 @@ struct HostScene {
     int n_prims = 0, n_spheres = 0, n_quads = 0;
     int n_nodes = 0, bvh_depth = 0;
     bool linear = true;
+    bool any_chain = false; // some primitive sits inside instance wrappers
 };
 
 // flags: RT_SCENE_FORCE_* (rt_amd.h).  The descriptor must already be validated.
@@ -338,58 +339,51 @@ inline int flatten_scene(const rt_scene_desc *d, uint32_t flags, HostScene &out,
             first = d->chains[p.xform].first_op;
             last = first + d->chains[p.xform].n_ops;
         }
+        // A wrapped primitive keeps its object-space constants in either traversal: the ray is
+        // taken into object space when the primitive is tested, wrapper by wrapper, as the
+        // reference does (hittable.h:57-69, 251-269, 319-334).  A BVH only needs its world-space
+        // box: the corners of the object-space box pushed through the wrappers.
+        auto to_world = [&](f3 q) {
+            for (int k = first; k < last; k++) q = op_point(ops[k], q);
+            return q;
+        };
+        if (wrapped) out.any_chain = true;
         if (p.type == RT_PRIM_SPHERE) {
             f3 c1 = mk(p.a[0], p.a[1], p.a[2]);
             f3 cv = (p.flags & RT_PRIM_FLAG_MOVING) ? mk(p.b[0], p.b[1], p.b[2]) : mk(0.0f, 0.0f, 0.0f);
             float radius = p.c[0];
-            if (!linear && wrapped) {
-                // a translated / uniformly scaled sphere is still a sphere; anything else needs
-                // true instancing, which only the linear scan provides
-                for (int k = first; k < last; k++) {
-                    const HostOp &h = ops[k];
-                    if (h.type == RT_XF_TRANSLATE) {
-                        c1 = c1 + h.p;
-                    } else if (h.type == RT_XF_SCALE && h.p.x == h.p.y && h.p.y == h.p.z) {
-                        c1 = c1 * h.p;
-                        cv = cv * h.p;
-                        radius = radius * h.p.x;
-                    } else {
-                        err = "prim " + std::to_string(i) +
-                              ": rotated / non-uniformly scaled sphere inside a BVH scene";
-                        return RT_ERR_UNSUPPORTED;
-                    }
-                }
-            }
             g[0] = f4{c1.x, c1.y, c1.z, radius};
             g[1] = f4{cv.x, cv.y, cv.z, 0.0f};
             if (!linear) {
-                Box3 &b = boxes[i];
-                b.reset();
+                Box3 ob; // object space
+                ob.reset();
                 f3 rv = mk(std::fabs(radius), std::fabs(radius), std::fabs(radius));
                 f3 c2 = c1 + cv; // ray times lie in [0,1): c1 + t*cv stays between c1 and c1 + cv
-                b.add(c1 - rv);
-                b.add(c1 + rv);
-                b.add(c2 - rv);
-                b.add(c2 + rv);
+                ob.add(c1 - rv);
+                ob.add(c1 + rv);
+                ob.add(c2 - rv);
+                ob.add(c2 + rv);
+                Box3 &b = boxes[i];
+                if (!wrapped) {
+                    b = ob;
+                } else {
+                    b.reset();
+                    for (int corner = 0; corner < 8; corner++)
+                        b.add(to_world(mk((corner & 1) ? ob.hi[0] : ob.lo[0], (corner & 2) ? ob.hi[1] : ob.lo[1],
+                                          (corner & 4) ? ob.hi[2] : ob.lo[2])));
+                }
                 pad_box(b);
             }
         } else {
             f3 Q = mk(p.a[0], p.a[1], p.a[2]), u = mk(p.b[0], p.b[1], p.b[2]), v = mk(p.c[0], p.c[1], p.c[2]);
-            if (!linear && wrapped) { // fold the wrappers into the quad: an affine image of a
-                for (int k = first; k < last; k++) { // parallelogram is a parallelogram
-                    Q = op_point(ops[k], Q);
-                    u = op_vector(ops[k], u);
-                    v = op_vector(ops[k], v);
-                }
-            }
             quad_slot(Q, u, v, g);
             if (!linear) {
                 Box3 &b = boxes[i];
                 b.reset();
-                b.add(Q);
-                b.add(Q + u);
-                b.add(Q + v);
-                b.add(Q + u + v);
+                b.add(to_world(Q));
+                b.add(to_world(Q + u));
+                b.add(to_world(Q + v));
+                b.add(to_world(Q + u + v));
                 pad_box(b);
             }
         }
@@ -415,7 +409,7 @@ inline int flatten_scene(const rt_scene_desc *d, uint32_t flags, HostScene &out,
         for (int sl = 0; sl < n; sl++) {
             int pi = bo.leaf_order[sl];
             memcpy(&slots[(size_t)sl * slot_f4], &geom[(size_t)pi * slot_f4], sizeof(f4) * slot_f4);
-            meta[sl] = i4{types[pi], d->prims[pi].material, -1, pi};
+            meta[sl] = i4{types[pi], d->prims[pi].material, d->prims[pi].xform, pi};
         }
         out.n_nodes = (int)(nodes.size() / 4);
         out.bvh_depth = bo.max_inner_depth + 1;

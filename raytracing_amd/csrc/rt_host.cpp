@@ -307,7 +307,7 @@ int rt_scene_create(const rt_scene_desc *d, int device, uint32_t flags, rt_scene
     s->info.n_prims = n;
     s->info.n_spheres = hs.n_spheres;
     s->info.n_quads = hs.n_quads;
-    s->lean = hs.n_quads == 0 && !env_int("RT_AMD_NO_LEAN", 0);
+    s->lean = hs.n_quads == 0 && !hs.any_chain && !env_int("RT_AMD_NO_LEAN", 0);
     for (const rt_texture &t : hs.textures) // the table holds only what a material can reach
         if (t.type == RT_TEX_NOISE || t.type == RT_TEX_IMAGE) s->lean = false;
     s->info.n_nodes = hs.n_nodes;
