@@ -265,6 +265,10 @@ int rt_render_device(rt_scene *scene, const rt_camera_desc *cam, const rt_render
 
 /* write_color / linear_to_gamma (color.h:11-32): rgb8 = int(256*clamp(sqrt(scale*c),0,0.999)). */
 int rt_tonemap_u8(const float *accum, int64_t n_pixels, float scale, uint8_t *rgb8);
+/* The same on the device: d_accum and d_rgb8 are device pointers on `device`, the kernel is
+ * enqueued on `stream` (the image can stay in HBM until the 3 bytes per pixel are wanted). */
+int rt_tonemap_u8_device(int device, const float *d_accum, int64_t n_pixels, float scale, uint8_t *d_rgb8,
+                         void *stream);
 
 /* Per-launch timing of the render kernel: between begin and end the library
  * brackets every render-kernel launch of this scene with HIP events on the

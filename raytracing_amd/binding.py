@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(os.path.dirname(os.path.
 # every symbol include/rt_amd.h declares
 EXPORTS = ["rt_last_error", "rt_abi_version", "rt_device_count", "rt_camera_initialize",
            "rt_scene_create", "rt_scene_destroy", "rt_scene_get_info", "rt_trace_batch",
-           "rt_trace_batch_device", "rt_render", "rt_render_device", "rt_tonemap_u8",
+           "rt_trace_batch_device", "rt_render", "rt_render_device", "rt_tonemap_u8", "rt_tonemap_u8_device",
            "rt_profile_begin", "rt_profile_end", "rt_scene_file_save", "rt_scene_file_load",
            "rt_scene_file_free"]
 
@@ -54,6 +54,7 @@ def lib():
                                        C.POINTER(abi.RenderOpts), C.c_void_p, C.c_void_p,
                                        C.POINTER(abi.RenderStats)]
         L.rt_tonemap_u8.argtypes = [C.c_void_p, C.c_int64, C.c_float, C.c_void_p]
+        L.rt_tonemap_u8_device.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p]
         L.rt_profile_begin.argtypes = [C.c_void_p]
         L.rt_profile_end.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.rt_scene_file_save.argtypes = [C.POINTER(abi.SceneDesc), C.c_char_p]
@@ -83,6 +84,12 @@ def tonemap_u8(accum, scale):
     out = np.zeros(accum.shape, np.uint8)
     check(lib().rt_tonemap_u8(accum.ctypes.data, accum.size // 3, scale, out.ctypes.data))
     return out
+
+
+def tonemap_u8_device(device, d_accum_ptr, n_pixels, scale, d_rgb8_ptr, stream=0):
+    """Device pointers in, device bytes out (e.g. torch tensors' data_ptr())."""
+    check(lib().rt_tonemap_u8_device(device, C.c_void_p(d_accum_ptr), n_pixels, scale, C.c_void_p(d_rgb8_ptr),
+                                     C.c_void_p(stream)))
 
 
 class Scene:

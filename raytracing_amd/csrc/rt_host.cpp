@@ -647,6 +647,16 @@ int rt_tonemap_u8(const float *accum, int64_t n_pixels, float scale, uint8_t *rg
     return RT_OK;
 }
 
+int rt_tonemap_u8_device(int device, const float *d_accum, int64_t n_pixels, float scale, uint8_t *d_rgb8,
+                         void *stream) {
+    if (n_pixels < 0 || n_pixels > (1ll << 36) || (n_pixels > 0 && (!d_accum || !d_rgb8)))
+        return fail(RT_ERR_ARG, "bad argument");
+    int rc = set_device(device);
+    if (rc != RT_OK) return rc;
+    RT_HIP(rtl::launch_tonemap(d_accum, n_pixels * 3, scale, d_rgb8, (hipStream_t)stream));
+    return RT_OK;
+}
+
 // Per-launch timing of the render kernel between begin and end (HIP events on the
 // stream the launches go to).  end returns the summed time and the launch count.
 int rt_profile_begin(rt_scene *s) {

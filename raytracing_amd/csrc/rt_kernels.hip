@@ -340,6 +340,16 @@ __global__ void __launch_bounds__(256) reduce_stage(const f4 *stage, int n_pixel
         atomicAdd(ray_count, wave_rays[0] + wave_rays[1] + wave_rays[2] + wave_rays[3]);
 }
 
+// write_color (color.h:17-32) for one colour component per lane.
+__global__ void __launch_bounds__(256) tonemap_u8(const float *accum, long long n, float scale, uint8_t *rgb8) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float c = scale * accum[i];
+    float g = c > 0.0f ? sqrtf(c) : 0.0f;
+    g = g < 0.000f ? 0.000f : (g > 0.999f ? 0.999f : g);
+    rgb8[i] = (uint8_t) int(256 * g);
+}
+
 template <int TRAV>
 __global__ void __launch_bounds__(RT_TRACE_THREADS)
 trace_batch(DevScene sc, const rt_ray *rays, long long n_rays, float tmin, float tmax, rt_hit *hits) {
@@ -477,6 +487,14 @@ hipError_t launch_reduce(const f4 *stage, int n_pixels, int sample_count, float 
     int grid = (n_pixels + 255) / 256;
     hipLaunchKernelGGL(reduce_stage, dim3(grid), dim3(256), 0, stream, stage, n_pixels, sample_count, accum,
                        ray_count);
+    return hipGetLastError();
+}
+
+hipError_t launch_tonemap(const float *accum, long long n_components, float scale, uint8_t *rgb8,
+                          hipStream_t stream) {
+    if (n_components <= 0) return hipSuccess;
+    long long grid = (n_components + 255) / 256;
+    hipLaunchKernelGGL(tonemap_u8, dim3((unsigned)grid), dim3(256), 0, stream, accum, n_components, scale, rgb8);
     return hipGetLastError();
 }
 

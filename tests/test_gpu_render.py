@@ -138,3 +138,27 @@ def test_counters_and_depth_limit():
     z, stz = sc.render(cam0, 2, seed=1)
     assert stz.rays == 0 and not z.any()
     sc.close()
+
+
+def test_device_tonemap_equals_host_write_color():
+    """rt_tonemap_u8_device against rt_tonemap_u8 (color.h:17-32) on a rendered accumulation
+    image and on values around every 8-bit threshold."""
+    import torch
+    B = _binding()
+    arrays, cam, _ = load_scene("quads")
+    cam.image_width = 96
+    sc = B.Scene(arrays)
+    acc, _ = sc.render(cam, 16, seed=4)
+    sc.close()
+    edges = (np.arange(0, 257, dtype=np.float32) / np.float32(256)) ** 2
+    probe = np.concatenate([np.nextafter(edges, np.float32(0)), edges, np.nextafter(edges, np.float32(2)),
+                            np.float32([-1.0, 0.0, 1e-30, 4.0, np.inf])]).astype(np.float32)
+    probe = np.resize(probe, (len(probe) + 2) // 3 * 3)
+    for data, scale in ((acc.reshape(-1), 1.0 / 16), (probe, 1.0)):
+        host = B.tonemap_u8(data, scale)
+        d_in = torch.from_numpy(data.copy()).cuda()
+        d_out = torch.zeros(data.size, dtype=torch.uint8, device="cuda")
+        B.tonemap_u8_device(0, d_in.data_ptr(), data.size // 3, scale, d_out.data_ptr(),
+                            torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(d_out.cpu().numpy(), host.reshape(-1))
