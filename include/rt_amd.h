@@ -185,6 +185,8 @@ enum { RT_MODE_MEGAKERNEL = 0, RT_MODE_WAVEFRONT = 1 };
 #define RT_SCENE_FORCE_BVH 1u      /* rt_scene_create: build a BVH even for tiny scenes */
 #define RT_SCENE_FORCE_LINEAR 2u   /* never build a BVH (linear scan in test order)   */
 #define RT_SCENE_FORCE_GLOBAL 4u   /* keep scene arrays in HBM even if they fit LDS   */
+#define RT_SCENE_BUILD_DEVICE 8u   /* build the BVH on the GPU (linear BVH: fast to build,
+                                      a little slower to traverse than the host's SAH tree) */
 
 typedef struct rt_render_opts {
     int32_t sample_begin; /* first global sample index rendered by this call */
@@ -220,6 +222,8 @@ typedef struct rt_scene_info {
     int32_t bvh_depth;
     int32_t lds_resident; /* 1 if geometry is staged into LDS by the kernels */
     uint64_t device_bytes;
+    float build_ms;       /* flattening + BVH build (host or device), without the upload */
+    int32_t built_on_device; /* 1 if the BVH came from the device builder */
 } rt_scene_info;
 
 typedef struct rt_scene rt_scene; /* opaque: owns the device copy of one scene */
@@ -243,6 +247,10 @@ int rt_camera_initialize(const rt_camera_desc *cam, rt_camera_frame *out);
 int rt_scene_create(const rt_scene_desc *desc, int device, uint32_t flags, rt_scene **out);
 int rt_scene_destroy(rt_scene *scene);
 int rt_scene_get_info(const rt_scene *scene, rt_scene_info *out);
+/* Diagnostic (no counterpart in the reference): copies the scene's BVH nodes back to the host,
+ * n_nodes x 64 bytes: {c0.xyz h0.x}{h0.yz c1.xy}{c1.z h1.xyz}{ref0 ref1 - -} with c/h the centre
+ * and half extent of the two child boxes; ref >= 0 inner node, ref < 0 leaf ~(slot*2 + type). */
+int rt_scene_read_nodes(rt_scene *scene, void *out, uint64_t bytes);
 
 /* Replaces world.hit(r, interval(tmin, tmax), rec) (camera.h:148) for a batch
  * of rays: closest hit per ray.  Host buffers; the library stages them. */

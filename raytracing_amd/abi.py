@@ -18,7 +18,7 @@ RT_GROUP_LIST, RT_GROUP_BVH = 0, 1
 RT_PRIM_FLAG_MOVING = 1
 RT_MODE_MEGAKERNEL, RT_MODE_WAVEFRONT = 0, 1
 RT_RENDER_COUNTERS = 1
-RT_SCENE_FORCE_BVH, RT_SCENE_FORCE_LINEAR, RT_SCENE_FORCE_GLOBAL = 1, 2, 4
+RT_SCENE_FORCE_BVH, RT_SCENE_FORCE_LINEAR, RT_SCENE_FORCE_GLOBAL, RT_SCENE_BUILD_DEVICE = 1, 2, 4, 8
 
 f3 = C.c_float * 3
 
@@ -96,7 +96,7 @@ class RenderStats(C.Structure):
 class SceneInfo(C.Structure):
     _fields_ = [("n_prims", C.c_int32), ("n_spheres", C.c_int32), ("n_quads", C.c_int32),
                 ("n_nodes", C.c_int32), ("bvh_depth", C.c_int32), ("lds_resident", C.c_int32),
-                ("device_bytes", C.c_uint64)]
+                ("device_bytes", C.c_uint64), ("build_ms", C.c_float), ("built_on_device", C.c_int32)]
 
 
 class SceneArrays:

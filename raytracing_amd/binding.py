@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(os.path.dirname(os.path.
 
 # every symbol include/rt_amd.h declares
 EXPORTS = ["rt_last_error", "rt_abi_version", "rt_device_count", "rt_camera_initialize",
-           "rt_scene_create", "rt_scene_destroy", "rt_scene_get_info", "rt_trace_batch",
+           "rt_scene_create", "rt_scene_destroy", "rt_scene_get_info", "rt_scene_read_nodes", "rt_trace_batch",
            "rt_trace_batch_device", "rt_render", "rt_render_device", "rt_tonemap_u8", "rt_tonemap_u8_device",
            "rt_profile_begin", "rt_profile_end", "rt_scene_file_save", "rt_scene_file_load",
            "rt_scene_file_free"]
@@ -44,6 +44,7 @@ def lib():
                                       C.POINTER(C.c_void_p)]
         L.rt_scene_destroy.argtypes = [C.c_void_p]
         L.rt_scene_get_info.argtypes = [C.c_void_p, C.POINTER(abi.SceneInfo)]
+        L.rt_scene_read_nodes.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         L.rt_trace_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
                                      C.c_void_p]
         L.rt_trace_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
@@ -114,6 +115,12 @@ class Scene:
         i = abi.SceneInfo()
         check(lib().rt_scene_get_info(self.handle, C.byref(i)))
         return i
+
+    def nodes(self):
+        """The BVH nodes as an (n_nodes, 16) float32 array (refs are the bit patterns of [:, 12:14])."""
+        out = np.zeros((self.info().n_nodes, 16), np.float32)
+        check(lib().rt_scene_read_nodes(self.handle, out.ctypes.data, out.nbytes))
+        return out
 
     def trace(self, rays, tmin=0.001, tmax=np.inf):
         rays = np.ascontiguousarray(rays, abi.RAY_DT)

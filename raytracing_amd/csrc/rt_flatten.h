@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -142,9 +143,10 @@ inline void center_half(const Box3 &b, float *c, float *h) {
 // Binned-SAH BVH2 builder.  Leaves hold one primitive; a parent stores the boxes
 // of both children (one 64-byte fetch tests both).
 struct BvhOut {
-    std::vector<f4> nodes;       // 4 per node
+    std::vector<f4> nodes;       // 4 per node (empty if an external builder keeps them elsewhere)
     std::vector<int> leaf_order; // slot -> input primitive index
     int max_inner_depth = 0;
+    int n_nodes = 0;             // set by external builders; the host builder's is nodes.size() / 4
 };
 
 class BvhBuilder {
@@ -309,10 +311,17 @@ struct HostScene {
     int n_nodes = 0, bvh_depth = 0;
     bool linear = true;
     bool any_chain = false; // some primitive sits inside instance wrappers
+    bool external_nodes = false; // the nodes were built (and are kept) by the external builder
 };
 
 // flags: RT_SCENE_FORCE_* (rt_amd.h).  The descriptor must already be validated.
-inline int flatten_scene(const rt_scene_desc *d, uint32_t flags, HostScene &out, std::string &err) {
+// An external builder (the device-side one) gets the padded world-space boxes and the
+// primitive types and fills leaf_order, max_inner_depth and n_nodes; returning false falls
+// back to the host builder.
+using ExternalBuilder = std::function<bool(const std::vector<Box3> &, const std::vector<int> &, BvhOut &)>;
+
+inline int flatten_scene(const rt_scene_desc *d, uint32_t flags, HostScene &out, std::string &err,
+                         const ExternalBuilder &external = nullptr) {
     const int n = d->n_prims;
     bool linear = n <= kLinearMaxPrims;
     if (flags & RT_SCENE_FORCE_BVH) linear = n < 2;
@@ -402,8 +411,19 @@ inline int flatten_scene(const rt_scene_desc *d, uint32_t flags, HostScene &out,
         slots = geom;
         for (int i = 0; i < n; i++) meta[i] = i4{types[i], d->prims[i].material, d->prims[i].xform, i};
     } else {
-        BvhBuilder builder(boxes, types);
-        BvhOut bo = builder.run();
+        BvhOut bo;
+        bool built = false;
+        if (external) {
+            built = external(boxes, types, bo) && (int)bo.leaf_order.size() == n &&
+                    bo.max_inner_depth <= kMaxInnerDepth;
+            if (!built) bo = BvhOut();
+        }
+        if (!built) {
+            BvhBuilder builder(boxes, types);
+            bo = builder.run();
+            bo.n_nodes = (int)(bo.nodes.size() / 4);
+        }
+        out.external_nodes = built;
         nodes = std::move(bo.nodes);
         slots.resize((size_t)n * slot_f4);
         for (int sl = 0; sl < n; sl++) {
@@ -411,7 +431,7 @@ inline int flatten_scene(const rt_scene_desc *d, uint32_t flags, HostScene &out,
             memcpy(&slots[(size_t)sl * slot_f4], &geom[(size_t)pi * slot_f4], sizeof(f4) * slot_f4);
             meta[sl] = i4{types[pi], d->prims[pi].material, d->prims[pi].xform, pi};
         }
-        out.n_nodes = (int)(nodes.size() / 4);
+        out.n_nodes = bo.n_nodes;
         out.bvh_depth = bo.max_inner_depth + 1;
     }
 

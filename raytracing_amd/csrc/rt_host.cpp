@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -287,11 +288,35 @@ int rt_scene_create(const rt_scene_desc *d, int device, uint32_t flags, rt_scene
     if (rc != RT_OK) return rc;
 
     rtf::HostScene hs;
+    float *d_built_nodes = nullptr; // RT_SCENE_BUILD_DEVICE: the tree stays where it was built
+    const auto t_build0 = std::chrono::steady_clock::now();
     {
         std::string err;
-        rc = rtf::flatten_scene(d, flags, hs, err);
-        if (rc != RT_OK) return fail(rc, "%s", err.c_str());
+        rtf::ExternalBuilder device_builder = nullptr;
+        if ((flags & RT_SCENE_BUILD_DEVICE) || env_int("RT_AMD_BUILD_DEVICE", 0))
+            device_builder = [&](const std::vector<rtf::Box3> &boxes, const std::vector<int> &types, rtf::BvhOut &bo) {
+                static_assert(sizeof(rtf::Box3) == 6 * sizeof(float), "Box3 is six floats");
+                const int np = (int)boxes.size();
+                bo.leaf_order.resize((size_t)np);
+                int levels = 0;
+                hipError_t e = rtl::build_lbvh(reinterpret_cast<const float *>(boxes.data()), types.data(), np,
+                                               &d_built_nodes, bo.leaf_order.data(), &levels);
+                if (e != hipSuccess) return false; // host builder takes over
+                bo.max_inner_depth = levels - 1;
+                bo.n_nodes = np - 1;
+                return true;
+            };
+        rc = rtf::flatten_scene(d, flags, hs, err, device_builder);
+        if (rc != RT_OK) {
+            if (d_built_nodes) hipFree(d_built_nodes);
+            return fail(rc, "%s", err.c_str());
+        }
+        if (d_built_nodes && !hs.external_nodes) { // built, then rejected (too deep): host tree in use
+            hipFree(d_built_nodes);
+            d_built_nodes = nullptr;
+        }
     }
+    const double build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build0).count();
     const int n = hs.n_prims;
     const bool linear = hs.linear;
     const int slot_f4 = hs.slot_f4;
@@ -312,6 +337,8 @@ int rt_scene_create(const rt_scene_desc *d, int device, uint32_t flags, rt_scene
         if (t.type == RT_TEX_NOISE || t.type == RT_TEX_IMAGE) s->lean = false;
     s->info.n_nodes = hs.n_nodes;
     s->info.bvh_depth = hs.bvh_depth;
+    s->info.build_ms = (float)build_ms;
+    s->info.built_on_device = hs.external_nodes ? 1 : 0;
 
     const std::vector<rt_texture> &texs = hs.textures;
     std::vector<rt_perlin> perl(d->perlins, d->perlins + d->n_perlins);
@@ -319,10 +346,15 @@ int rt_scene_create(const rt_scene_desc *d, int device, uint32_t flags, rt_scene
     std::vector<uint8_t> texels(d->texels, d->texels + d->n_texel_bytes);
 
     rtc::DevScene &dv = s->dev;
+    if (d_built_nodes) { // the scene owns the device-built tree from here on
+        dv.nodes = reinterpret_cast<const f4 *>(d_built_nodes);
+        s->allocs.push_back(d_built_nodes);
+        s->info.device_bytes += (size_t)hs.n_nodes * 4 * sizeof(f4);
+    }
     rc = upload(s, slots, &dv.slots);
     if (rc == RT_OK) rc = upload(s, rec_i, &dv.rec_i);
     if (rc == RT_OK) rc = upload(s, rec_f, &dv.rec_f);
-    if (rc == RT_OK) rc = upload(s, nodes, &dv.nodes);
+    if (rc == RT_OK && !d_built_nodes) rc = upload(s, nodes, &dv.nodes);
     if (rc == RT_OK) rc = upload(s, xf_packed, &dv.xf);
     if (rc == RT_OK) rc = upload(s, chain_first, &dv.chain_first);
     if (rc == RT_OK) rc = upload(s, texs, &dv.textures);
@@ -345,7 +377,7 @@ int rt_scene_create(const rt_scene_desc *d, int device, uint32_t flags, rt_scene
     s->d_words = const_cast<unsigned long long *>(dw);
     s->d_counters = const_cast<rtc::Counters *>(dc);
     dv.n_slots = n;
-    dv.n_nodes = (int)(nodes.size() / 4);
+    dv.n_nodes = hs.n_nodes;
     dv.n_textures = (int)texs.size();
     dv.slot_f4 = slot_f4;
     dv.traversal = linear ? rtc::TRAV_LINEAR : rtc::TRAV_BVH;
@@ -374,6 +406,15 @@ int rt_scene_create(const rt_scene_desc *d, int device, uint32_t flags, rt_scene
                 s->pool_geom.lds_bytes, s->pool_geom.pool_slots);
     s->info.lds_resident = s->geom.lds_scene ? 1 : 0;
     *out = s;
+    return RT_OK;
+}
+
+int rt_scene_read_nodes(rt_scene *s, void *out, uint64_t bytes) {
+    if (!s || !out) return fail(RT_ERR_ARG, "null argument");
+    if (bytes != (uint64_t)s->info.n_nodes * 4 * sizeof(f4)) return fail(RT_ERR_ARG, "expected n_nodes * 64 bytes");
+    int rc = set_device(s->device);
+    if (rc != RT_OK) return rc;
+    if (bytes) RT_HIP(hipMemcpy(out, s->dev.nodes, bytes, hipMemcpyDeviceToHost));
     return RT_OK;
 }
 

@@ -74,6 +74,8 @@ int mega_waves_per_simd(); // register budget the render kernels were compiled f
 int mega_blocks_per_cu(int block, int lds_bytes, bool lds_scene);
 hipError_t launch_reduce(const rtc::f4 *stage, int n_pixels, int sample_count, float *accum,
                          unsigned long long *ray_count, hipStream_t stream);
+hipError_t build_lbvh(const float *boxes, const int *types, int n, float **d_nodes_out, int *leaf_order,
+                      int *inner_levels);
 hipError_t launch_tonemap(const float *accum, long long n_components, float scale, uint8_t *rgb8,
                           hipStream_t stream);
 hipError_t launch_trace(const rtc::DevScene &sc, const rt_ray *rays, long long n, float tmin, float tmax,

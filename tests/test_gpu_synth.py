@@ -147,3 +147,61 @@ def test_synth_full_grid(tmp_path):
     assert int(off.any(axis=2).sum()) <= 1e-4 * 480 * 270
     assert np.isfinite(a).all() and a.mean() > 0
     sc.close()
+
+
+def test_device_built_bvh(tmp_path):
+    """RT_SCENE_BUILD_DEVICE: the linear BVH built on the GPU must give the same closest hits
+    as the host's SAH tree (and as the exhaustive scan), on the golden BVH scene, on a scene
+    with instance wrappers, and on the synthetic grid at two sizes; images agree bit for bit
+    where no rounding-dominated hit is involved."""
+    from tests.conftest import load_scene
+    from tests.test_abi_and_host import instanced_rays, instanced_scene
+    B = _binding()
+    # bouncing_spheres: the reference's own ray records
+    arrays, cam, _ = load_scene("bouncing_spheres")
+    import os as _os
+    from tests.conftest import GOLDEN
+    rays, ref_hits, tmin, tmax = O.load_rays_file(_os.path.join(GOLDEN, "bouncing_spheres.rays"))
+    sc = B.Scene(arrays, flags=abi.RT_SCENE_BUILD_DEVICE)
+    info = sc.info()
+    assert info.built_on_device == 1 and info.n_nodes == len(arrays.prims) - 1 and info.bvh_depth <= 30
+    hits = sc.trace(rays, tmin, tmax)
+    assert np.array_equal(hits["prim"], ref_hits["prim"])
+    m = ref_hits["prim"] >= 0
+    assert np.array_equal(hits["t"][m], ref_hits["t"][m]) and np.array_equal(hits["p"][m], ref_hits["p"][m])
+    cam.image_width = 200
+    a, st = sc.render(cam, 8, seed=7)
+    sc.close()
+    sc = B.Scene(arrays)
+    assert sc.info().built_on_device == 0
+    b, st2 = sc.render(cam, 8, seed=7)
+    sc.close()
+    assert st.rays == st2.rays and np.array_equal(a, b)
+    # instances
+    arrays = instanced_scene()
+    rays = instanced_rays(100_000)
+    ref, _ = O.OracleScene(arrays).trace(rays, 0.001, np.inf, O.TRACE_REFERENCE)
+    sc = B.Scene(arrays, flags=abi.RT_SCENE_BUILD_DEVICE)
+    hits = sc.trace(rays)
+    assert np.array_equal(hits["prim"], ref["prim"]) and np.array_equal(hits["t"], ref["t"])
+    sc.close()
+    # the synthetic grid: reduced (against the exhaustive scan) and full (against the host tree)
+    arrays, cam = _synth(tmp_path, 60)
+    rng = np.random.default_rng(8)
+    rays = _camera_rays(cam, 4000, rng)
+    sc = B.Scene(arrays, flags=abi.RT_SCENE_BUILD_DEVICE)
+    hits = sc.trace(rays)
+    oh, _ = O.OracleScene(arrays).trace(rays, 0.001, np.inf, O.TRACE_REFERENCE)
+    _assert_same_hits(arrays, rays, hits, oh)
+    sc.close()
+    arrays, cam = _synth(tmp_path, 500)
+    rays = _camera_rays(cam, 200_000, rng)
+    dev = B.Scene(arrays, flags=abi.RT_SCENE_BUILD_DEVICE)
+    host = B.Scene(arrays)
+    di, hi = dev.info(), host.info()
+    print(f"synth1m build: device {di.build_ms:.0f} ms (depth {di.bvh_depth}), host {hi.build_ms:.0f} ms (depth {hi.bvh_depth})")
+    assert di.built_on_device == 1 and di.n_nodes == 1_000_000 and di.bvh_depth <= 30
+    hd, hh = dev.trace(rays), host.trace(rays)
+    _assert_same_hits(arrays, rays, hd, hh, max_frac=0.05)
+    dev.close()
+    host.close()

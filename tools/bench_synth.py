@@ -22,11 +22,12 @@ t1 = time.perf_counter()
 arrays = abi.SceneArrays.load(out)
 cam = abi.load_camera_file(out + ".cam")[0]
 t2 = time.perf_counter()
-sc = binding.Scene(arrays)
+sc = binding.Scene(arrays, flags=abi.RT_SCENE_BUILD_DEVICE if "--device-build" in sys.argv else 0)
 t3 = time.perf_counter()
 info = sc.info()
 print(f"prims {len(arrays.prims)}  scene program {t1-t0:.2f} s  load {t2-t1:.2f} s  "
-      f"rt_scene_create (flatten + SAH build + upload) {t3-t2:.2f} s  nodes {info.n_nodes} depth {info.bvh_depth} "
+      f"rt_scene_create {t3-t2:.2f} s (flatten + {'device LBVH' if info.built_on_device else 'host SAH'} build "
+      f"{info.build_ms/1e3:.2f} s, rest upload)  nodes {info.n_nodes} depth {info.bvh_depth} "
       f"device MB {info.device_bytes/1e6:.1f}", flush=True)
 H, W = cam.image_height(), cam.image_width
 acc = torch.zeros(H, W, 3, device="cuda")
