@@ -16,6 +16,22 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _torch_initialises_the_gpu_first():
+    """PyTorch's wheel carries its own copy of the HIP runtime.  When librt_amd.so (linked
+    against the system's) has been the first to touch the GPU in a process, torch's later
+    initialisation reports "No HIP GPUs are available"; the other order works (it is the order
+    of bench.py and of any torch program that calls into the library).  So on a GPU box torch
+    goes first."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
+    yield
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

@@ -149,6 +149,47 @@ def test_synth_full_grid(tmp_path):
     sc.close()
 
 
+def _tree_stats(nodes):
+    """Walks a BVH read back with rt_scene_read_nodes: inner levels, inner nodes reached, distinct
+    leaf slots, child boxes that stick out of their parent's box."""
+    refs = nodes[:, 12:14].view(np.int32)
+    seen = np.zeros(len(nodes), bool)
+    leaves, depth, outside = set(), 0, 0
+    todo = [(0, 1, None)]
+    while todo:
+        i, d, box = todo.pop()
+        assert not seen[i], "a node is reachable twice"
+        seen[i] = True
+        depth = max(depth, d)
+        nd = nodes[i]
+        centre = (nd[0:3], nd[6:9])
+        half = (np.r_[nd[3], nd[4:6]], nd[9:12])
+        for k in range(2):
+            lo, hi = centre[k] - half[k], centre[k] + half[k]
+            if box is not None and (np.any(lo < box[0] - 1e-3 * (1 + np.abs(box[0]))) or
+                                    np.any(hi > box[1] + 1e-3 * (1 + np.abs(box[1])))):
+                outside += 1
+            r = int(refs[i, k])
+            if r >= 0:
+                todo.append((r, d + 1, (lo, hi)))
+            else:
+                leaves.add((~r) >> 1)
+    return depth, int(seen.sum()), len(leaves), outside
+
+
+@pytest.mark.parametrize("flags", [0, abi.RT_SCENE_BUILD_DEVICE])
+def test_bvh_is_a_proper_tree(flags):
+    B = _binding()
+    from tests.conftest import load_scene
+    arrays, _, _ = load_scene("bouncing_spheres")
+    sc = B.Scene(arrays, flags=flags)
+    info = sc.info()
+    depth, inner, leaves, outside = _tree_stats(sc.nodes())
+    assert inner == info.n_nodes == len(arrays.prims) - 1 and leaves == len(arrays.prims)
+    assert depth == info.bvh_depth and outside == 0
+    sc.close()
+
+
 def test_device_built_bvh(tmp_path):
     """RT_SCENE_BUILD_DEVICE: the linear BVH built on the GPU must give the same closest hits
     as the host's SAH tree (and as the exhaustive scan), on the golden BVH scene, on a scene
