@@ -162,3 +162,72 @@ def test_device_tonemap_equals_host_write_color():
                             torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         assert np.array_equal(d_out.cpu().numpy(), host.reshape(-1))
+
+
+def test_odd_sizes_empty_and_single_primitive_scenes(monkeypatch):
+    """Image sizes that are no multiple of the 64-pixel strips, one-pixel images, a single
+    sample, depth 1, a scene without primitives (every path is background, camera.h:148-161)
+    and a single primitive, through every render variant; all against the oracle."""
+    B = _binding()
+    arrays, cam, _ = load_scene("bouncing_spheres")
+    osc = O.OracleScene(arrays)
+    sc = B.Scene(arrays)
+    for width, aspect, spp, depth in ((1, 1.0, 1, 50), (3, 0.2, 2, 1), (67, 67 / 45, 3, 4), (130, 1.3, 1, 50)):
+        c = cam.copy()
+        c.image_width, c.aspect_ratio, c.max_depth = width, aspect, depth
+        ref, ost = osc.render(c, spp, sampler=O.SAMPLER_CB, trace_mode=O.TRACE_REFERENCE, seed=2, n_threads=4)
+        for mode in (abi.RT_MODE_MEGAKERNEL, abi.RT_MODE_WAVEFRONT):
+            for sched in ("0", "1", "2"):
+                if mode == abi.RT_MODE_WAVEFRONT and sched != "1":
+                    continue
+                monkeypatch.setenv("RT_AMD_SCHEDULER", sched)
+                acc, st = sc.render(c, spp, seed=2, mode=mode)
+                assert acc.shape == ref.shape and st.paths == ost.paths
+                frac = float((np.abs(acc - ref) > 1e-4 * np.maximum(1.0, np.abs(ref))).any(axis=2).mean())
+                assert frac <= max(0.03, 1.5 / acc[..., 0].size), (width, spp, depth, mode, sched, frac)
+    sc.close()
+    monkeypatch.delenv("RT_AMD_SCHEDULER")
+    # no primitives: background everywhere, exactly
+    empty = abi.SceneArrays(prims=np.zeros(0, abi.PRIM_DT), materials=arrays.materials, textures=arrays.textures)
+    sc = B.Scene(empty)
+    c = cam.copy()
+    c.image_width = 40
+    for mode in (abi.RT_MODE_MEGAKERNEL, abi.RT_MODE_WAVEFRONT):
+        acc, st = sc.render(c, 3, mode=mode)
+        assert st.rays == st.paths == acc[..., 0].size * 3
+        assert np.array_equal(acc, np.broadcast_to(np.float32(3) * np.array(list(cam.background), np.float32), acc.shape))
+    assert (sc.trace(np.zeros(5, abi.RAY_DT))["prim"] == -1).all()
+    sc.close()
+    # one primitive, with and without a forced BVH (a tree needs two leaves: falls back to the scan)
+    one = abi.SceneArrays(prims=arrays.prims[:1], materials=arrays.materials, textures=arrays.textures)
+    o1 = O.OracleScene(one)
+    ref, _ = o1.render(c, 2, sampler=O.SAMPLER_CB, trace_mode=O.TRACE_REFERENCE, seed=1, n_threads=2)
+    for flags in (0, abi.RT_SCENE_FORCE_BVH, abi.RT_SCENE_BUILD_DEVICE | abi.RT_SCENE_FORCE_BVH):
+        sc = B.Scene(one, flags=flags)
+        acc, _ = sc.render(c, 2, seed=1)
+        assert float((np.abs(acc - ref) > 1e-4 * np.maximum(1.0, np.abs(ref))).any(axis=2).mean()) < 0.02
+        sc.close()
+
+
+def test_render_argument_errors():
+    B = _binding()
+    arrays, cam, _ = load_scene("quads")
+    sc = B.Scene(arrays)
+    c = cam.copy()
+    c.image_width = 0
+    with pytest.raises(B.RtError):
+        sc.render(c, 1)
+    c = cam.copy()
+    c.max_depth = -1
+    with pytest.raises(B.RtError):
+        sc.render(c, 1)
+    with pytest.raises(B.RtError):
+        sc.render(cam, -1)
+    with pytest.raises(B.RtError) as e:
+        sc.render(cam, 1, mode=7)
+    assert e.value.code == abi.RT_ERR_UNSUPPORTED
+    acc, st = sc.render(cam, 0)          # zero samples: nothing to do, not an error
+    assert not acc.any() and st.paths == 0
+    sc.close()
+    with pytest.raises(B.RtError):
+        B.Scene(arrays, device=99)
