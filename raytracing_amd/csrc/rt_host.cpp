@@ -552,8 +552,8 @@ int rt_render_device(rt_scene *s, const rt_camera_desc *cam, const rt_render_opt
         rp.pool_slots = lg.pool_slots;
         rp.dispatch_min = std::max(1, std::min(64, env_int("RT_AMD_DISPATCH_MIN", 8)));
         rp.min_ready = std::max(1, std::min(64, env_int("RT_AMD_MIN_READY", 40)));
-        rp.leaf_min = std::max(1, std::min(64, env_int("RT_AMD_LEAF_MIN", 24)));
-        rp.blocked_min = std::max(1, std::min(64, env_int("RT_AMD_BLOCKED_MIN", 8)));
+        rp.leaf_min = std::max(1, std::min(64, env_int("RT_AMD_LEAF_MIN", 8)));
+        rp.blocked_min = std::max(1, std::min(64, env_int("RT_AMD_BLOCKED_MIN", 2)));
         rp.regen_min = std::max(1, std::min(64, env_int("RT_AMD_REGEN_MIN", 1)));
         RT_HIP(hipMemsetAsync(s->d_words, 0, sizeof(unsigned long long), stream));
         hipEvent_t p0 = nullptr, p1 = nullptr;
