@@ -69,8 +69,8 @@ def test_reference_random_stream():
 
 def test_committed_sample_render_mean():
     """The reference ships one render (RayTracing.png: cornell_box, 600x600, 10 spp, made with
-    another toolchain's random stream).  Only its mean survives a different stream: the SURVEY
-    measured (32.34, 26.34, 22.26) on its 8-bit pixels.  The oracle's own 10 spp render with
+    another toolchain's random stream).  Only its mean survives a different stream: its 8-bit
+    pixels average (32.34, 26.34, 22.26).  The oracle's own 10 spp render with
     the counter-based sampler must land on the same mean radiance."""
     arrays, cam, _ = load_scene("cornell_box")
     cam.image_width = 150
