@@ -71,10 +71,11 @@ def cpu_baseline(scene, budget_paths):
     cam, _ = abi.load_camera_file(os.path.join(GOLD, scene + ".cam"))
     w, h = cam.image_width, cam.image_height()
     spp = max(1, int(round(budget_paths / (w * h))))
-    if os.path.exists(ref_bin) and scene != "earth":  # earth needs the texture file at run time
+    if os.path.exists(ref_bin):
         try:
+            env = dict(os.environ, RTW_IMAGES=os.path.join(GOLD, "images"))  # earth's texture file
             out = subprocess.run([ref_bin, "render", scene, str(spp), "0", "0", "0", "-"], check=True,
-                                 capture_output=True, cwd="/tmp", timeout=600)
+                                 capture_output=True, cwd="/tmp", timeout=600, env=env)
             m = json.loads(out.stdout.decode().strip().splitlines()[-1])
             return {"value": m["mpaths_per_s"], "unit": "Mpaths/s", "cores": 1, "kind": "reference",
                     "mrays_per_s": m["mrays_per_s"],
@@ -101,7 +102,7 @@ def main():
     ap.add_argument("--spp", type=int, default=100, help="samples per pixel per step per GPU")
     ap.add_argument("--width", type=int, default=0, help="override image width (0: the scene's own)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-paths", type=float, default=4.5e6, help="paths of the CPU baseline sample")
+    ap.add_argument("--cpu-paths", type=float, default=13.5e6, help="paths of the CPU baseline sample")
     args = ap.parse_args()
 
     import torch
