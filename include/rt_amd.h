@@ -267,7 +267,9 @@ int rt_trace_batch_device(rt_scene *scene, const rt_ray *d_rays, int64_t n_rays,
 int rt_render(rt_scene *scene, const rt_camera_desc *cam, const rt_render_opts *opts,
               float *accum_host, rt_render_stats *stats);
 /* accum lives in device memory; kernels are enqueued on `stream`.  With
- * stats == NULL the call does not synchronise. */
+ * stats == NULL the megakernel call does not synchronise (RT_MODE_WAVEFRONT polls its
+ * queue counters and does).  A scene owns the per-launch scratch (path records, queues), so
+ * calls on one scene must be ordered: one stream at a time. */
 int rt_render_device(rt_scene *scene, const rt_camera_desc *cam, const rt_render_opts *opts,
                      float *d_accum, void *stream, rt_render_stats *stats);
 

@@ -244,3 +244,24 @@ def test_empty_and_degenerate_scenes():
     assert (hits["prim"] == -1).all()
     h2, _ = O.OracleScene(arrays).trace(rays)
     assert (h2["prim"] == -1).all()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_kernel_logic_on_random_scenes(seed):
+    """Random scenes with every primitive, material, texture and wrapper kind: the kernel logic
+    (scan and tree) against the oracle's emulation of the reference, hit records bit for bit
+    and a small render path for path."""
+    from tests.scene_fuzz import random_rays, random_scene
+    arrays, cam = random_scene(seed, n_prims=40 + 25 * seed)
+    rays = random_rays(seed, 6000)
+    osc = O.OracleScene(arrays)
+    ref, _ = osc.trace(rays, 0.001, np.inf, O.TRACE_REFERENCE)
+    assert (ref["prim"] > 0).mean() > 0.05
+    for flags in (0, abi.RT_SCENE_FORCE_LINEAR):
+        hits, _, _ = S.SimScene(arrays, flags).trace(rays)
+        assert hits.tobytes() == ref.tobytes(), flags
+    cam.image_width = 40
+    acc, n_rays = S.SimScene(arrays).render(cam, 2, seed=seed)
+    want, st = osc.render(cam, 2, sampler=O.SAMPLER_CB, trace_mode=O.TRACE_REFERENCE, seed=seed)
+    assert n_rays == st.rays
+    assert np.allclose(acc, want, rtol=2e-6, atol=1e-7)
