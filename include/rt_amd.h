@@ -214,6 +214,9 @@ typedef struct rt_render_stats {
     /* wave cycles of the decoupled render kernel (RT_RENDER_COUNTERS, BVH scenes), summed
      * over waves: whole kernel, shading, starting paths, node steps, leaf tests */
     uint64_t cycles[6];
+    /* wall-clock profile of the decoupled kernel's launch, microseconds after the first wave
+     * started: first / last wave that found the launch out of new paths, last wave exit */
+    double tail_us[3];
 } rt_render_stats;
 
 typedef struct rt_scene_info {

@@ -90,7 +90,7 @@ class RenderStats(C.Structure):
                 ("quad_tests", C.c_uint64), ("shades", C.c_uint64 * 4),
                 ("noise_evals", C.c_uint64), ("image_evals", C.c_uint64),
                 ("checker_evals", C.c_uint64), ("sched", C.c_uint64 * 6), ("kernel_ms", C.c_double),
-                ("cycles", C.c_uint64 * 6)]
+                ("cycles", C.c_uint64 * 6), ("tail_us", C.c_double * 3)]
 
 
 class SceneInfo(C.Structure):

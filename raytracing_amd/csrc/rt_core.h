@@ -159,6 +159,9 @@ struct Counters {
     // active in them, leaf-block executions / lanes, shading phases / lanes
     unsigned long long sched[6];
     unsigned long long cycles[6]; // wave cycles: whole kernel, shading, starting paths, node steps, leaf tests
+    // wall clock (100 MHz ticks): earliest wave start, first / last moment a wave found the launch
+    // out of new paths, last wave exit
+    unsigned long long tail[4];
 };
 
 template <bool COUNT> struct Cnt {

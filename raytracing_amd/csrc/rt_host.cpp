@@ -47,7 +47,7 @@ int fail(int code, const char *fmt, ...) {
         if (e_ != hipSuccess) return fail(RT_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_));     \
     } while (0)
 
-const int kMaxLdsBytes = 160 * 1024; // LDS per CU on gfx950
+const int kMaxLdsBytes = 160 * 1024 - RT_BLOCK_POOL_BYTES; // LDS per CU on gfx950, less the kernels' static part
 
 } // namespace
 
@@ -58,8 +58,21 @@ struct rt_scene {
     rt_scene_info info;
     std::vector<void *> allocs;
     // render scratch (owned by the scene, grown on demand)
-    f4 *stage = nullptr;
-    size_t stage_bytes = 0;
+    // two sets of per-launch scratch: consecutive megakernel launches go to two internal
+    // streams, so that launch k+1 fills the CUs that the tail of launch k (its last long
+    // paths) leaves idle; the reduction into the caller's image stays on the caller's stream
+    f4 *stage[2] = {nullptr, nullptr};
+    size_t stage_bytes[2] = {0, 0};
+    hipStream_t mega_stream[2] = {nullptr, nullptr};
+    hipEvent_t ev_done[2] = {nullptr, nullptr}; // megakernel finished (recorded on its internal stream)
+    hipEvent_t ev_free[2] = {nullptr, nullptr}; // the set's records have been reduced (caller's stream)
+    bool ev_free_valid[2] = {false, false};
+    int flip = 0;
+    // tail hand-over of pipelined launches (RenderParams::spill): per set, the batches and their counts
+    f4 *spill[2] = {nullptr, nullptr};
+    unsigned *spill_count[2] = {nullptr, nullptr};
+    int spill_waves = 0, spill_max = 0;
+    unsigned epoch = 0;
     unsigned long long *d_words = nullptr; // [0] pool counter, [1] ray counter
     rtc::Counters *d_counters = nullptr;
     int n_cu = 256;
@@ -268,7 +281,15 @@ int rt_scene_destroy(rt_scene *s) {
     if (!s) return RT_OK;
     hipSetDevice(s->device);
     for (void *p : s->allocs) hipFree(p);
-    if (s->stage) hipFree(s->stage);
+    hipDeviceSynchronize();
+    for (int b = 0; b < 2; b++) {
+        if (s->stage[b]) hipFree(s->stage[b]);
+        if (s->spill[b]) hipFree(s->spill[b]);
+        if (s->spill_count[b]) hipFree(s->spill_count[b]);
+        if (s->mega_stream[b]) hipStreamDestroy(s->mega_stream[b]);
+        if (s->ev_done[b]) hipEventDestroy(s->ev_done[b]);
+        if (s->ev_free[b]) hipEventDestroy(s->ev_free[b]);
+    }
     if (s->wf_mem) hipFree(s->wf_mem);
     if (s->wf_host_cnt) hipHostFree(s->wf_host_cnt);
     for (hipEvent_t e : s->prof_events) hipEventDestroy(e);
@@ -361,7 +382,7 @@ int rt_scene_create(const rt_scene_desc *d, int device, uint32_t flags, rt_scene
     if (rc == RT_OK) rc = upload(s, perl, &dv.perlins);
     if (rc == RT_OK) rc = upload(s, imgs, &dv.images);
     if (rc == RT_OK) rc = upload(s, texels, &dv.texels);
-    std::vector<unsigned long long> words(4, 0ull);
+    std::vector<unsigned long long> words(8, 0ull); // 0 / 2: pool counters, 1: rays, 4 / 5: batch counters
     const unsigned long long *dw = nullptr;
     if (rc == RT_OK) rc = upload(s, words, &dw);
     std::vector<rtc::Counters> cnt(1);
@@ -501,13 +522,16 @@ int rt_render_device(rt_scene *s, const rt_camera_desc *cam, const rt_render_opt
     size_t per_sample = (size_t)n_pixels * sizeof(f4);
     int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)opts->sample_count, stage_budget_bytes() / per_sample));
     size_t need = per_sample * chunk;
-    if (need > s->stage_bytes) {
-        if (s->stage) RT_HIP(hipFree(s->stage));
-        s->stage = nullptr;
-        s->stage_bytes = 0;
-        RT_HIP(hipMalloc((void **)&s->stage, need));
-        s->stage_bytes = need;
-    }
+    auto ensure_stage = [&](int b) -> int {
+        if (need > s->stage_bytes[b]) {
+            if (s->stage[b]) RT_HIP(hipFree(s->stage[b])); // (synchronises the device)
+            s->stage[b] = nullptr;
+            s->stage_bytes[b] = 0;
+            RT_HIP(hipMalloc((void **)&s->stage[b], need));
+            s->stage_bytes[b] = need;
+        }
+        return RT_OK;
+    };
 
     const bool count = (opts->flags & RT_RENDER_COUNTERS) != 0 && stats != nullptr;
     // BVH scenes: 1 = decoupled (default), 0 = whole ray, 2 = path pool in LDS (experimental)
@@ -531,11 +555,57 @@ int rt_render_device(rt_scene *s, const rt_camera_desc *cam, const rt_render_opt
         RT_HIP(hipEventCreate(&ev0));
         RT_HIP(hipEventCreate(&ev1));
         RT_HIP(hipMemsetAsync(s->d_words + 1, 0, sizeof(unsigned long long), stream));
-        if (count) RT_HIP(hipMemsetAsync(s->d_counters, 0, sizeof(rtc::Counters), stream));
+        if (count) {
+            rtc::Counters zero;
+            memset(&zero, 0, sizeof(zero));
+            zero.tail[0] = zero.tail[1] = ~0ull; // minima
+            RT_HIP(hipMemcpyAsync(s->d_counters, &zero, sizeof(zero), hipMemcpyHostToDevice, stream));
+            RT_HIP(hipStreamSynchronize(stream)); // `zero` lives on this stack frame
+        }
     }
+    // pipelined launches: megakernel only, and not when the caller wants per-call statistics
+    const bool pipelined = !wavefront && scheduler != 2 && !stats && env_int("RT_AMD_PIPELINE", 1) != 0;
     float mega_ms = 0.0f;
     for (int done = 0; done < opts->sample_count; done += chunk) {
         int sc_n = std::min(chunk, opts->sample_count - done);
+        const int b = pipelined ? s->flip : 0;
+        if (pipelined) s->flip ^= 1;
+        rc = ensure_stage(b);
+        if (rc != RT_OK) return rc;
+        hipStream_t ms = stream; // the stream the render kernel goes to
+        if (pipelined) {
+            if (!s->mega_stream[b]) {
+                RT_HIP(hipStreamCreateWithFlags(&s->mega_stream[b], hipStreamNonBlocking));
+                RT_HIP(hipEventCreateWithFlags(&s->ev_done[b], hipEventDisableTiming));
+                RT_HIP(hipEventCreateWithFlags(&s->ev_free[b], hipEventDisableTiming));
+            }
+            ms = s->mega_stream[b];
+            // tail hand-over: only BVH scenes with the decoupled scheduler have it
+            const int want_spill = std::max(0, std::min(64, env_int("RT_AMD_SPILL_MAX", 16)));
+            const int waves = lg.grid * (lg.block / 64);
+            if (want_spill > 0 && s->dev.traversal == rtc::TRAV_BVH && scheduler == 1 &&
+                (s->spill_waves < waves || s->spill_max < want_spill)) {
+                for (int k = 0; k < 2; k++) {
+                    if (s->spill[k]) RT_HIP(hipFree(s->spill[k]));
+                    if (s->spill_count[k]) RT_HIP(hipFree(s->spill_count[k]));
+                    s->spill[k] = nullptr;
+                    s->spill_count[k] = nullptr;
+                    RT_HIP(hipMalloc((void **)&s->spill[k], (size_t)waves * want_spill * RT_SPILL_F4 * sizeof(f4)));
+                    RT_HIP(hipMalloc((void **)&s->spill_count[k], (size_t)waves * sizeof(unsigned)));
+                    RT_HIP(hipMemset(s->spill_count[k], 0, (size_t)waves * sizeof(unsigned)));
+                }
+                s->spill_waves = waves;
+                s->spill_max = want_spill;
+                s->epoch = 0;
+            }
+            // this set's previous records must have been reduced; nothing else orders the
+            // render kernel (it reads only the scene and writes only this set)
+            if (s->ev_free_valid[b]) RT_HIP(hipStreamWaitEvent(ms, s->ev_free[b], 0));
+        } else if (s->ev_free_valid[0] || s->ev_free_valid[1]) {
+            // a non-pipelined launch after pipelined ones reuses set 0 on the caller's stream
+            for (int k = 0; k < 2; k++)
+                if (s->ev_free_valid[k]) RT_HIP(hipStreamWaitEvent(stream, s->ev_free[k], 0));
+        }
         RenderParams rp;
         rp.width = W;
         rp.height = H;
@@ -543,35 +613,56 @@ int rt_render_device(rt_scene *s, const rt_camera_desc *cam, const rt_render_opt
         rp.sample_begin = opts->sample_begin + done;
         rp.sample_count = sc_n;
         rp.seed = opts->seed;
-        rp.n_sample_groups = ((unsigned)sc_n + RT_POOL_SAMPLES - 1) / RT_POOL_SAMPLES;
-        rp.n_chunks = (unsigned)((n_pixels + 63) / 64) * rp.n_sample_groups;
-        rp.stage = s->stage;
-        rp.next_chunk = reinterpret_cast<unsigned *>(s->d_words);
+        rp.n_strips = (unsigned)((n_pixels + 63) / 64);
+        rp.n_units = rp.n_strips * (unsigned)sc_n;
+        rp.stage = s->stage[b];
+        rp.next_chunk = reinterpret_cast<unsigned *>(s->d_words + 2 * b); // words 0 / 2: pool counters, 1: rays
         rp.counters = count ? s->d_counters : nullptr;
         rp.scheduler = scheduler;
+        rp.spill = nullptr;
+        rp.spill_count = nullptr;
+        rp.next_batch = nullptr;
+        rp.epoch = 0;
+        rp.spill_max = 0;
+        rp.n_server_blocks = 0;
+        if (pipelined && s->spill[b] && s->dev.traversal == rtc::TRAV_BVH && scheduler == 1) {
+            const int servers = std::max(1, std::min(lg.grid / 4, env_int("RT_AMD_TAIL_BLOCKS", 16)));
+            const int want_spill = std::max(0, std::min(s->spill_max, env_int("RT_AMD_SPILL_MAX", 16)));
+            if (want_spill > 0 && lg.grid > servers) {
+                s->epoch = (s->epoch + 1) & 0xffffffu;
+                if (s->epoch == 0) s->epoch = 1;
+                rp.spill = s->spill[b];
+                rp.spill_count = s->spill_count[b];
+                rp.next_batch = reinterpret_cast<unsigned *>(s->d_words + 4 + b);
+                rp.epoch = s->epoch;
+                rp.spill_max = want_spill;
+                rp.n_server_blocks = servers;
+                RT_HIP(hipMemsetAsync(s->d_words + 4 + b, 0, sizeof(unsigned long long), ms));
+            }
+        }
         rp.pool_slots = lg.pool_slots;
         rp.dispatch_min = std::max(1, std::min(64, env_int("RT_AMD_DISPATCH_MIN", 8)));
         rp.min_ready = std::max(1, std::min(64, env_int("RT_AMD_MIN_READY", 40)));
         rp.leaf_min = std::max(1, std::min(64, env_int("RT_AMD_LEAF_MIN", 8)));
         rp.blocked_min = std::max(1, std::min(64, env_int("RT_AMD_BLOCKED_MIN", 2)));
         rp.regen_min = std::max(1, std::min(64, env_int("RT_AMD_REGEN_MIN", 1)));
-        RT_HIP(hipMemsetAsync(s->d_words, 0, sizeof(unsigned long long), stream));
+        RT_HIP(hipMemsetAsync(s->d_words + 2 * b, 0, sizeof(unsigned long long), ms));
         hipEvent_t p0 = nullptr, p1 = nullptr;
         if (s->profiling) {
             RT_HIP(hipEventCreate(&p0));
             RT_HIP(hipEventCreate(&p1));
-            RT_HIP(hipEventRecord(p0, stream));
+            RT_HIP(hipEventRecord(p0, ms));
         }
         if (stats) RT_HIP(hipEventRecord(ev0, stream));
         if (!wavefront) {
             if (scheduler == 2)
-                RT_HIP(rtl::launch_pool(dev, dc, rp, lg, stream));
+                RT_HIP(rtl::launch_pool(dev, dc, rp, lg, ms));
             else if (s->lean)
-                RT_HIP(rtl::launch_mega_lean(dev, dc, rp, lg, stream));
+                RT_HIP(rtl::launch_mega_lean(dev, dc, rp, lg, ms));
             else
-                RT_HIP(rtl::launch_mega(dev, dc, rp, lg, stream));
+                RT_HIP(rtl::launch_mega(dev, dc, rp, lg, ms));
         } else if (dc.max_depth <= 0) { // camera.h:141: every path is black
-            RT_HIP(hipMemsetAsync(s->stage, 0, per_sample * sc_n, stream));
+            RT_HIP(hipMemsetAsync(s->stage[b], 0, per_sample * sc_n, stream));
         } else {
             int rounds = 0;
             RT_HIP(rtl::render_wavefront(dev, dc, rp, s->wf, wf_slots, lg, s->wf_host_cnt, stream, &rounds));
@@ -579,11 +670,19 @@ int rt_render_device(rt_scene *s, const rt_camera_desc *cam, const rt_render_opt
         }
         if (stats) RT_HIP(hipEventRecord(ev1, stream));
         if (s->profiling) {
-            RT_HIP(hipEventRecord(p1, stream));
+            RT_HIP(hipEventRecord(p1, ms));
             s->prof_events.push_back(p0);
             s->prof_events.push_back(p1);
         }
-        RT_HIP(rtl::launch_reduce(s->stage, n_pixels, sc_n, d_accum, s->d_words + 1, stream));
+        if (pipelined) { // the caller's stream takes over once the records are complete
+            RT_HIP(hipEventRecord(s->ev_done[b], ms));
+            RT_HIP(hipStreamWaitEvent(stream, s->ev_done[b], 0));
+        }
+        RT_HIP(rtl::launch_reduce(s->stage[b], n_pixels, sc_n, d_accum, s->d_words + 1, stream));
+        if (pipelined) {
+            RT_HIP(hipEventRecord(s->ev_free[b], stream));
+            s->ev_free_valid[b] = true;
+        }
         if (stats) {
             RT_HIP(hipEventSynchronize(ev1));
             float ms = 0.0f;
@@ -614,6 +713,9 @@ int rt_render_device(rt_scene *s, const rt_camera_desc *cam, const rt_render_opt
             stats->checker_evals = c.checker_evals;
             for (int k = 0; k < 6; k++) stats->sched[k] = c.sched[k];
             for (int k = 0; k < 6; k++) stats->cycles[k] = c.cycles[k];
+            if (c.tail[3] > c.tail[0] && c.tail[0] != ~0ull)
+                for (int k = 0; k < 3; k++) // wall_clock64 ticks at 100 MHz
+                    stats->tail_us[k] = c.tail[k + 1] == ~0ull ? 0.0 : (double)(c.tail[k + 1] - c.tail[0]) * 0.01;
         }
     }
     return RT_OK;

@@ -45,9 +45,12 @@ template <int TRAV, bool LDS_SCENE, bool COUNT>
 __global__ void __launch_bounds__(RT_MEGA_MAX_THREADS, RT_MEGA_WAVES_PER_SIMD)
 render_mega(DevScene sc, DevCamera cam, RenderParams rp) {
     extern __shared__ f4 smem[];
+    __shared__ BlockPool block_pool;
+    block_pool_init(&block_pool);
     SceneView vw = global_view(sc);
     f4 *free_lds = smem;
     if constexpr (LDS_SCENE) free_lds = stage_scene(sc, smem, vw);
+    else __syncthreads();
     using StackT = typename std::conditional<LDS_SCENE, short, int>::type;
     StackT *stack = reinterpret_cast<StackT *>(free_lds) + threadIdx.x;
     const int stack_stride = blockDim.x;
@@ -67,7 +70,7 @@ render_mega(DevScene sc, DevCamera cam, RenderParams rp) {
     for (;;) {
         unsigned long long need = __ballot(!alive);
         if (need != 0ull) {
-            pool_refill(wp, rp, lane);
+            pool_refill(wp, &block_pool, rp, lane);
             if (wp.k < wp.k_end) {
                 unsigned n_need = (unsigned)__popcll(need);
                 if (!alive) {
@@ -147,9 +150,12 @@ template <bool LDS_SCENE, bool COUNT>
 __global__ void __launch_bounds__(RT_MEGA_MAX_THREADS, RT_MEGA_WAVES_PER_SIMD)
 render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
     extern __shared__ f4 smem[];
+    __shared__ BlockPool block_pool;
+    block_pool_init(&block_pool);
     SceneView vw = global_view(sc);
     f4 *free_lds = smem;
     if constexpr (LDS_SCENE) free_lds = stage_scene(sc, smem, vw);
+    else __syncthreads();
     using StackT = typename std::conditional<LDS_SCENE, short, int>::type;
     StackT *stack = reinterpret_cast<StackT *>(free_lds) + threadIdx.x;
     const int stack_stride = blockDim.x;
@@ -170,15 +176,27 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
     Trav tv;
     unsigned pixel = 0, sample = 0, n_rays = 0;
     Cnt<COUNT> cn;
+    // tail hand-over (RenderParams::spill_max): producers give their last paths away, servers take them
+    const int spill_max = rp.spill_max;
+    const int waves_per_block = blockDim.x >> 6;
+    const bool is_server = spill_max > 0 && (int)blockIdx.x < rp.n_server_blocks;
+    const int producer = ((int)blockIdx.x - rp.n_server_blocks) * waves_per_block + (threadIdx.x >> 6);
+    const unsigned n_producers = (unsigned)((int)gridDim.x - rp.n_server_blocks) * (unsigned)waves_per_block;
+    bool batches_done = !is_server; // no batch left to claim
+    bool have_batch = false;
+    unsigned batch = 0;
     // wave-level schedule statistics (instrumented variant only), kept by lane 0
     unsigned long long w_t_iters = 0, w_t_lanes = 0, w_l_iters = 0, w_l_lanes = 0, w_s_phases = 0, w_s_lanes = 0;
     long long c_shade = 0, c_regen = 0, c_inner = 0, c_leaf = 0, c_mark = 0;
     const long long c_begin = COUNT ? clock64() : 0;
+    unsigned long long w_start = 0, w_dry = 0;
+    if constexpr (COUNT) w_start = wall_clock64();
 #define RT_TICK() if constexpr (COUNT) c_mark = clock64()
 #define RT_TOCK(acc) if constexpr (COUNT) acc += clock64() - c_mark
 
     for (;;) {
         if constexpr (COUNT) {
+            if (w_dry == 0 && wp.exhausted && wp.k >= wp.k_end) w_dry = wall_clock64();
             unsigned long long rm = __ballot(state == ST_READY);
             if (rm) {
                 w_s_phases++;
@@ -208,33 +226,110 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
         // starting paths (camera ray, sampler seed) is batched like everything else: wait
         // until regen_min lanes are idle unless nothing else is left to do
         if (need != 0ull && (__popcll(need) >= regen_min || !__any(state == ST_TRAV))) {
-            pool_refill(wp, rp, lane);
-            if (wp.k < wp.k_end) {
-                unsigned n_need = (unsigned)__popcll(need);
-                if (state == ST_IDLE) {
-                    unsigned k = wp.k + (unsigned)__popcll(need & lane_mask_lt);
-                    int px, py;
-                    unsigned pix, s_local;
-                    if (k < wp.k_end && pool_decode(wp, rp, k, pix, s_local, px, py)) {
-                        pixel = pix;
-                        sample = s_local;
-                        ps = path_start(cam, rp.seed, pixel, px, py, (unsigned)rp.sample_begin + s_local);
-                        if (ps.depth > 0) {
-                            n_rays = 1;
-                            trav_begin(tv, ps.ray, RT_INF);
-                            state = ST_TRAV;
-                        } else { // max_depth 0: camera.h:141
-                            write_record(rp, sample, pixel, mk(0.0f, 0.0f, 0.0f), 0u);
-                        }
-                    }
+            // the idle lanes take consecutive paths; a unit that runs out half-way is followed
+            // by the next one at once, so that all of them start together below
+            bool want = state == ST_IDLE, start = false;
+            int px = 0, py = 0;
+            for (int pass = 0; pass < 2 && need != 0ull; pass++) {
+                pool_refill(wp, &block_pool, rp, lane);
+                if (!(wp.k < wp.k_end)) break;
+                const unsigned avail = wp.k_end - wp.k;
+                const unsigned n_need = (unsigned)__popcll(need);
+                const unsigned r = (unsigned)__popcll(need & lane_mask_lt);
+                const bool mine = want && r < avail;
+                if (mine) {
+                    start = pool_decode(wp, rp, wp.k + r, pixel, sample, px, py);
+                    want = false;
                 }
-                wp.k = wp.k + n_need < wp.k_end ? wp.k + n_need : wp.k_end;
+                wp.k += n_need < avail ? n_need : avail;
+                need &= ~__ballot(mine);
+            }
+            if (start) {
+                ps = path_start(cam, rp.seed, pixel, px, py, (unsigned)rp.sample_begin + sample);
+                if (ps.depth > 0) {
+                    n_rays = 1;
+                    trav_begin(tv, ps.ray, RT_INF);
+                    state = ST_TRAV;
+                } else { // max_depth 0: camera.h:141
+                    write_record(rp, sample, pixel, mk(0.0f, 0.0f, 0.0f), 0u);
+                }
             }
         }
         RT_TOCK(c_regen);
         const bool pool_dry = wp.exhausted && wp.k >= wp.k_end;
+        if (spill_max > 0 && pool_dry) {
+            if (!is_server) {
+                // ---- producer: down to a few paths, hand them over and leave ------------------------
+                unsigned long long live = __ballot(state == ST_TRAV);
+                int n_live = __popcll(live);
+                if (n_live <= spill_max && !__any(state == ST_READY)) {
+                    if (state == ST_TRAV) { // the ray is traced again from its origin by the server
+                        f4 *rec = rp.spill + ((size_t)producer * spill_max + __popcll(live & lane_mask_lt)) * RT_SPILL_F4;
+                        rec[0] = f4{ps.ray.o.x, ps.ray.o.y, ps.ray.o.z, ps.ray.tm};
+                        rec[1] = f4{ps.ray.d.x, ps.ray.d.y, ps.ray.d.z, 0.0f};
+                        rec[2] = f4{ps.beta.x, ps.beta.y, ps.beta.z, __builtin_bit_cast(float, ps.rng.s)};
+                        rec[3] = f4{ps.L.x, ps.L.y, ps.L.z,
+                                    __builtin_bit_cast(float, ((unsigned)ps.depth & 0xffffu) | (n_rays << 16))};
+                        rec[4] = f4{__builtin_bit_cast(float, pixel), __builtin_bit_cast(float, sample), 0.0f, 0.0f};
+                    }
+                    __threadfence(); // the records are visible before the count says so
+                    if (lane == 0)
+                        __hip_atomic_store(&rp.spill_count[producer], (rp.epoch << 8) | (unsigned)n_live, __ATOMIC_RELEASE,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            } else if (!batches_done) {
+                // ---- server: take the next producer's batch once spill_max lanes are free -----------
+                unsigned long long idle = __ballot(state == ST_IDLE);
+                if (__popcll(idle) >= spill_max) {
+                    if (!have_batch) {
+                        unsigned b = 0;
+                        if (lane == 0) b = atomicAdd(rp.next_batch, 1u);
+                        batch = wave_bcast32(b);
+                        have_batch = true;
+                        if (batch >= n_producers) batches_done = true;
+                    }
+                    if (!batches_done) {
+                        unsigned v = 0;
+                        if (lane == 0)
+                            v = __hip_atomic_load(&rp.spill_count[batch], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                        v = wave_bcast32(v);
+                        if ((v >> 8) == rp.epoch) { // that wave has left: its batch is complete
+                            __threadfence();
+                            const int n_rec = (int)(v & 0xffu);
+                            const int r = __popcll(idle & lane_mask_lt);
+                            if (state == ST_IDLE && r < n_rec) {
+                                const f4 *rec = rp.spill + ((size_t)batch * spill_max + r) * RT_SPILL_F4;
+                                const f4 a0 = rec[0], a1 = rec[1], a2 = rec[2], a3 = rec[3], a4 = rec[4];
+                                ps.ray.o = mk(a0.x, a0.y, a0.z);
+                                ps.ray.tm = a0.w;
+                                ps.ray.d = mk(a1.x, a1.y, a1.z);
+                                ps.beta = mk(a2.x, a2.y, a2.z);
+                                ps.rng.s = __builtin_bit_cast(unsigned, a2.w);
+                                ps.L = mk(a3.x, a3.y, a3.z);
+                                const unsigned packed = __builtin_bit_cast(unsigned, a3.w);
+                                ps.depth = (int)(packed & 0xffffu);
+                                n_rays = packed >> 16;
+                                pixel = __builtin_bit_cast(unsigned, a4.x);
+                                sample = __builtin_bit_cast(unsigned, a4.y);
+                                trav_begin(tv, ps.ray, RT_INF);
+                                pend = 0;
+                                state = ST_TRAV;
+                            }
+                            have_batch = false;
+                        } else if (!__any(state != ST_IDLE)) {
+                            __builtin_amdgcn_s_sleep(32); // nothing else to do: wait for that wave
+                        }
+                    }
+                }
+            }
+        }
         if (!__any(state != ST_IDLE)) {
-            if (pool_dry) break;
+            if (pool_dry && batches_done) {
+                if (spill_max > 0 && !is_server && lane == 0) // a producer that finished everything itself
+                    __hip_atomic_store(&rp.spill_count[producer], rp.epoch << 8, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
             continue;
         }
         // ---- traversal steps until enough lanes wait for shading ------------------------------
@@ -305,6 +400,10 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
             atomicAdd(&rp.counters->cycles[2], (unsigned long long)c_regen);
             atomicAdd(&rp.counters->cycles[3], (unsigned long long)c_inner);
             atomicAdd(&rp.counters->cycles[4], (unsigned long long)c_leaf);
+            atomicMin(&rp.counters->tail[0], w_start);
+            atomicMin(&rp.counters->tail[1], w_dry ? w_dry : ~0ull);
+            atomicMax(&rp.counters->tail[2], w_dry);
+            atomicMax(&rp.counters->tail[3], (unsigned long long)wall_clock64());
         }
     }
 }

@@ -13,15 +13,22 @@
 #define RT_POOL_MAX_THREADS 512  // render_pool_bvh: 2 waves per SIMD, up to 256 VGPRs
 #define RT_POOL_WAVES_PER_SIMD 2
 #define RT_POOL_SLOT_F4 5        // 80-byte path slots of render_pool_bvh
-#define RT_POOL_SAMPLES 4u // a wave reserves 64 pixels x this many samples from the global counter
+#define RT_SPILL_F4 5            // 80-byte records of paths handed over at the tail of a launch
+#ifndef RT_POOL_MAX_UNITS
+#define RT_POOL_MAX_UNITS 32u // a workgroup reserves at most this many units of 64 paths at a time
+#endif
+#ifndef RT_POOL_GUIDE_DIV
+#define RT_POOL_GUIDE_DIV 2u // ... and at most 1/RT_POOL_GUIDE_DIV of its share of what is left
+#endif
+#define RT_BLOCK_POOL_BYTES 64 // static LDS of the render kernels besides the dynamic part
 
 struct RenderParams {
     int width, height, n_pixels;
     int sample_begin; // global index of the first sample of this launch
     int sample_count; // samples per pixel in this launch
     uint32_t seed;
-    unsigned n_sample_groups;      // ceil(sample_count / RT_POOL_SAMPLES)
-    unsigned n_chunks;             // ceil(n_pixels / 64) * n_sample_groups
+    unsigned n_strips;             // ceil(n_pixels / 64)
+    unsigned n_units;              // n_strips * sample_count: units of 64 paths (rt_wavepool.h)
     rtc::f4 *stage;                // [sample_count][n_pixels] {r g b rays}
     unsigned *next_chunk;          // pool counter, zeroed before the launch
     rtc::Counters *counters;       // non-null: count tests (instrumented kernel variant)
@@ -30,6 +37,16 @@ struct RenderParams {
     int leaf_min;  // decoupled: lanes that must hold a parked leaf before the leaf block runs
     int blocked_min; // decoupled: ... or this many lanes stalled on a second leaf
     int regen_min;   // decoupled: idle lanes that must accumulate before new paths are started
+    // Tail hand-over of the decoupled kernel (spill_max > 0): once the launch has no new paths
+    // left, a wave of a block >= n_server_blocks that is down to spill_max live paths writes
+    // them to its batch in `spill` and exits, so that its CU is free for the next launch; the
+    // waves of the first n_server_blocks blocks pick the batches up and finish them.
+    rtc::f4 *spill;          // [producer wave][spill_max] path records of RT_SPILL_F4 x 16 bytes
+    unsigned *spill_count;   // [producer wave] (epoch << 8) | records, written once when the wave exits
+    unsigned *next_batch;    // next batch to hand to a server wave, zeroed before the launch
+    unsigned epoch;          // distinguishes this launch's spill_count entries from older ones
+    int spill_max;
+    int n_server_blocks;
     int pool_slots;   // path pool: path slots per wave (LDS)
     int dispatch_min; // path pool: idle engines that must accumulate before pending rays are handed out
 };

@@ -54,14 +54,17 @@ __device__ __forceinline__ void list_push(unsigned short *list, int &n, bool pre
 // of paths started (wave-uniform).
 template <bool COUNT>
 __device__ __forceinline__ int start_paths(bool want, int slot, f4 *pool, WaveLists &wl, WavePool &wp,
-                                           const DevCamera &cam, const RenderParams &rp, int lane,
+                                           BlockPool *bp, const DevCamera &cam, const RenderParams &rp, int lane,
                                            unsigned long long lane_mask_lt) {
     int started = 0;
     for (;;) {
         unsigned long long need = __ballot(want);
         if (need == 0ull) break;
-        pool_refill(wp, rp, lane);
-        if (!(wp.k < wp.k_end)) break; // the launch has no paths left
+        pool_refill(wp, bp, rp, lane);
+        if (!(wp.k < wp.k_end)) {
+            if (wp.exhausted) break; // the launch has no paths left
+            continue;                // the workgroup's next run is on its way: a slot left empty stays empty
+        }
         unsigned n_need = (unsigned)__popcll(need);
         bool begun = false;
         if (want) {
@@ -97,9 +100,12 @@ template <bool LDS_SCENE, bool COUNT>
 __global__ void __launch_bounds__(RT_POOL_MAX_THREADS, RT_POOL_WAVES_PER_SIMD)
 render_pool_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
     extern __shared__ f4 smem[];
+    __shared__ BlockPool block_pool;
+    block_pool_init(&block_pool);
     SceneView vw = global_view(sc);
     f4 *free_lds = smem;
     if constexpr (LDS_SCENE) free_lds = stage_scene(sc, smem, vw);
+    else __syncthreads();
     using StackT = typename std::conditional<LDS_SCENE, short, int>::type;
 
     const int lane = threadIdx.x & 63;
@@ -146,7 +152,7 @@ render_pool_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
     RT_TICK();
     for (int base = 0; base < M; base += 64) {
         int slot = base + lane;
-        n_live += start_paths<COUNT>(slot < M, slot, pool, wl, wp, cam, rp, lane, lane_mask_lt);
+        n_live += start_paths<COUNT>(slot < M, slot, pool, wl, wp, &block_pool, cam, rp, lane, lane_mask_lt);
     }
     RT_TOCK(c_regen);
 
@@ -200,7 +206,7 @@ render_pool_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
             // a finished path hands its slot to a new camera path while the launch has any
             const int n_ended = __popcll(__ballot(ended));
             if (n_ended > 0)
-                n_live += start_paths<COUNT>(ended, slot, pool, wl, wp, cam, rp, lane, lane_mask_lt) - n_ended;
+                n_live += start_paths<COUNT>(ended, slot, pool, wl, wp, &block_pool, cam, rp, lane, lane_mask_lt) - n_ended;
             RT_TOCK(c_regen);
             continue;
         }
