@@ -182,6 +182,8 @@ typedef struct rt_hit {
 enum { RT_MODE_MEGAKERNEL = 0, RT_MODE_WAVEFRONT = 1 };
 
 #define RT_RENDER_COUNTERS 1u      /* fill the per-test counters of rt_render_stats */
+#define RT_RENDER_NO_OVERLAP 2u    /* keep this call's launches on the caller's stream: no overlap
+                                    * with the launches before and after (isolated kernel timing) */
 #define RT_SCENE_FORCE_BVH 1u      /* rt_scene_create: build a BVH even for tiny scenes */
 #define RT_SCENE_FORCE_LINEAR 2u   /* never build a BVH (linear scan in test order)   */
 #define RT_SCENE_FORCE_GLOBAL 4u   /* keep scene arrays in HBM even if they fit LDS   */

@@ -142,10 +142,12 @@ class Scene:
         return accum, st
 
     def render_device(self, cam, sample_count, d_accum_ptr, stream=0, sample_begin=0, seed=0,
-                      counters=False, want_stats=False, mode=abi.RT_MODE_MEGAKERNEL):
-        """Device-buffer render: d_accum_ptr is a device address (e.g. tensor.data_ptr())."""
+                      counters=False, want_stats=False, mode=abi.RT_MODE_MEGAKERNEL, overlap=True):
+        """Device-buffer render: d_accum_ptr is a device address (e.g. tensor.data_ptr()).
+        overlap=False keeps the launches on `stream` alone (RT_RENDER_NO_OVERLAP)."""
         o = abi.RenderOpts(sample_begin, sample_count, seed, mode,
-                           abi.RT_RENDER_COUNTERS if counters else 0)
+                           (abi.RT_RENDER_COUNTERS if counters else 0) |
+                           (0 if overlap else abi.RT_RENDER_NO_OVERLAP))
         st = abi.RenderStats() if (want_stats or counters) else None
         check(lib().rt_render_device(self.handle, C.byref(cam), C.byref(o), C.c_void_p(d_accum_ptr),
                                      C.c_void_p(stream), C.byref(st) if st is not None else None))

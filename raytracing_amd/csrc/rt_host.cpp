@@ -47,6 +47,7 @@ int fail(int code, const char *fmt, ...) {
         if (e_ != hipSuccess) return fail(RT_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_));     \
     } while (0)
 
+const int kTimelineLaunches = 32;
 const int kMaxLdsBytes = 160 * 1024 - RT_BLOCK_POOL_BYTES; // LDS per CU on gfx950, less the kernels' static part
 
 } // namespace
@@ -84,6 +85,11 @@ struct rt_scene {
     unsigned wf_slots = 0;
     WfBuffers wf;
     unsigned *wf_host_cnt = nullptr; // pinned
+    // RT_AMD_TIMELINE=<file>: per-wave wall-clock records of the last kTimelineLaunches launches,
+    // written to the file when the scene is destroyed (tools/timeline.py reads it)
+    unsigned long long *d_timeline = nullptr;
+    int timeline_waves = 0, timeline_block_waves = 0;
+    long long timeline_launches = 0;
     // optional per-launch timing of the render kernel
     bool profiling = false;
     std::vector<hipEvent_t> prof_events; // pairs
@@ -289,6 +295,22 @@ int rt_scene_destroy(rt_scene *s) {
         if (s->mega_stream[b]) hipStreamDestroy(s->mega_stream[b]);
         if (s->ev_done[b]) hipEventDestroy(s->ev_done[b]);
         if (s->ev_free[b]) hipEventDestroy(s->ev_free[b]);
+    }
+    if (s->d_timeline) {
+        const char *path = getenv("RT_AMD_TIMELINE");
+        const size_t words = (size_t)kTimelineLaunches * s->timeline_waves * 4;
+        std::vector<unsigned long long> host(words + 4);
+        host[0] = (unsigned long long)std::min<long long>(s->timeline_launches, kTimelineLaunches);
+        host[1] = (unsigned long long)s->timeline_waves;
+        host[2] = (unsigned long long)s->timeline_block_waves;
+        host[3] = (unsigned long long)s->timeline_launches; // the ring's next position is this modulo its size
+        if (path && hipMemcpy(host.data() + 4, s->d_timeline, words * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            if (FILE *f = fopen(path, "wb")) {
+                fwrite(host.data(), 8, host.size(), f);
+                fclose(f);
+            }
+        }
+        hipFree(s->d_timeline);
     }
     if (s->wf_mem) hipFree(s->wf_mem);
     if (s->wf_host_cnt) hipHostFree(s->wf_host_cnt);
@@ -564,7 +586,8 @@ int rt_render_device(rt_scene *s, const rt_camera_desc *cam, const rt_render_opt
         }
     }
     // pipelined launches: megakernel only, and not when the caller wants per-call statistics
-    const bool pipelined = !wavefront && scheduler != 2 && !stats && env_int("RT_AMD_PIPELINE", 1) != 0;
+    const bool pipelined = !wavefront && scheduler != 2 && !stats && !(opts->flags & RT_RENDER_NO_OVERLAP) &&
+                           env_int("RT_AMD_PIPELINE", 1) != 0;
     float mega_ms = 0.0f;
     for (int done = 0; done < opts->sample_count; done += chunk) {
         int sc_n = std::min(chunk, opts->sample_count - done);
@@ -639,6 +662,18 @@ int rt_render_device(rt_scene *s, const rt_camera_desc *cam, const rt_render_opt
                 rp.n_server_blocks = servers;
                 RT_HIP(hipMemsetAsync(s->d_words + 4 + b, 0, sizeof(unsigned long long), ms));
             }
+        }
+        rp.timeline = nullptr;
+        if (!wavefront && scheduler == 1 && s->dev.traversal == rtc::TRAV_BVH && getenv("RT_AMD_TIMELINE")) {
+            const int waves = lg.grid * (lg.block / 64);
+            if (!s->d_timeline) {
+                RT_HIP(hipMalloc((void **)&s->d_timeline, (size_t)kTimelineLaunches * waves * 32));
+                RT_HIP(hipMemset(s->d_timeline, 0, (size_t)kTimelineLaunches * waves * 32));
+                s->timeline_waves = waves;
+                s->timeline_block_waves = lg.block / 64;
+            }
+            if (waves == s->timeline_waves)
+                rp.timeline = s->d_timeline + (size_t)(s->timeline_launches++ % kTimelineLaunches) * waves * 4;
         }
         rp.pool_slots = lg.pool_slots;
         rp.dispatch_min = std::max(1, std::min(64, env_int("RT_AMD_DISPATCH_MIN", 8)));

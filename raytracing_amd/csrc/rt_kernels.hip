@@ -191,6 +191,8 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
     const long long c_begin = COUNT ? clock64() : 0;
     unsigned long long w_start = 0, w_dry = 0;
     if constexpr (COUNT) w_start = wall_clock64();
+    const bool timeline = rp.timeline != nullptr;
+    unsigned long long tl_start = timeline ? wall_clock64() : 0ull, tl_dry = 0ull;
 #define RT_TICK() if constexpr (COUNT) c_mark = clock64()
 #define RT_TOCK(acc) if constexpr (COUNT) acc += clock64() - c_mark
 
@@ -257,6 +259,7 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
         }
         RT_TOCK(c_regen);
         const bool pool_dry = wp.exhausted && wp.k >= wp.k_end;
+        if (timeline && tl_dry == 0ull && pool_dry) tl_dry = wall_clock64();
         if (spill_max > 0 && pool_dry) {
             if (!is_server) {
                 // ---- producer: down to a few paths, hand them over and leave ------------------------
@@ -385,6 +388,15 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
             RT_TOCK(c_leaf);
             if (trav && tv.ref == RT_TRAV_DONE && pend == 0) state = ST_READY;
         }
+    }
+    if (timeline && lane == 0) {
+        unsigned long long *t = rp.timeline + 4u * ((size_t)blockIdx.x * waves_per_block + (threadIdx.x >> 6));
+        t[0] = tl_start;
+        t[1] = tl_dry;
+        t[2] = wall_clock64();
+        // HW_REG_HW_ID (4) and HW_REG_XCC_ID (20), all 32 bits of each
+        t[3] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) |
+               ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);
     }
     if constexpr (COUNT) {
         flush_counters<COUNT>(rp.counters, cn);

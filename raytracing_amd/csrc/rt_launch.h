@@ -47,6 +47,9 @@ struct RenderParams {
     unsigned epoch;          // distinguishes this launch's spill_count entries from older ones
     int spill_max;
     int n_server_blocks;
+    // Debugging aid (non-null): every wave of the decoupled kernel leaves {start, out of new
+    // paths, exit} in 100 MHz wall-clock ticks and its hardware id, 4 x 8 bytes per wave.
+    unsigned long long *timeline;
     int pool_slots;   // path pool: path slots per wave (LDS)
     int dispatch_min; // path pool: idle engines that must accumulate before pending rays are handed out
 };

@@ -38,12 +38,13 @@ def render_split(render_fn, accum, spp_total, dst=0, group=None):
     return begin, count
 
 
-def gpu_render_fn(scene, cam, seed=0):
-    """render_fn for a raytracing_amd.binding.Scene and a CUDA accumulation tensor."""
+def gpu_render_fn(scene, cam, seed=0, overlap=True):
+    """render_fn for a raytracing_amd.binding.Scene and a CUDA accumulation tensor.
+    overlap=False: every launch runs alone on the current stream (isolated kernel timing)."""
     def fn(sample_begin, sample_count, accum):
         if not accum.is_cuda or accum.dtype != torch.float32 or not accum.is_contiguous():
             raise ValueError("accum must be a contiguous fp32 CUDA tensor")
         scene.render_device(cam, sample_count, accum.data_ptr(),
                             stream=torch.cuda.current_stream(accum.device).cuda_stream,
-                            sample_begin=sample_begin, seed=seed)
+                            sample_begin=sample_begin, seed=seed, overlap=overlap)
     return fn
