@@ -285,6 +285,33 @@ int rt_tonemap_u8(const float *accum, int64_t n_pixels, float scale, uint8_t *rg
 int rt_tonemap_u8_device(int device, const float *d_accum, int64_t n_pixels, float scale, uint8_t *d_rgb8,
                          void *stream);
 
+/* ---- film: a device-resident accumulation image rendered in passes ------
+ * No counterpart in the reference (camera.h:39-57 keeps one host image and writes it once at
+ * the end): a film holds the fp32 radiance sums of camera::render's pixel loop in HBM between
+ * calls, so that a render can proceed in passes of a few samples per pixel, hand out 8-bit
+ * snapshots (write_color, color.h:17-32) while the next pass is already running, and be
+ * checkpointed / resumed through its sums and sample count.  One host thread per film. */
+typedef struct rt_film rt_film;
+int rt_film_create(int device, int32_t width, int32_t height, rt_film **out); /* zeroed */
+int rt_film_destroy(rt_film *film);
+/* rt_render_device into the film on the film's own stream (asynchronous): adds samples
+ * [opts->sample_begin, +opts->sample_count) and counts them.  The camera's image size must be
+ * the film's. */
+int rt_film_render(rt_scene *scene, rt_film *film, const rt_camera_desc *cam, const rt_render_opts *opts);
+/* Asynchronous: after everything rendered so far, tone-maps sums / samples to 3 bytes per pixel
+ * on the device and copies them (and, if with_accum != 0, the sums themselves) to pinned host
+ * memory on a second stream.  Passes rendered after this call overlap the copies; their
+ * accumulation waits for the copy of the sums.  One snapshot at a time: a second call waits
+ * for the first one's copies. */
+int rt_film_snapshot(rt_film *film, int with_accum);
+/* Waits for the last snapshot and copies it out: rgb8_out (width*height*3 bytes) and/or
+ * accum_out (width*height*3 floats; only after a snapshot with_accum) may be NULL;
+ * samples_out receives the samples per pixel the snapshot holds. */
+int rt_film_wait(rt_film *film, uint8_t *rgb8_out, float *accum_out, int64_t *samples_out);
+/* Replaces the film's contents (resume from a checkpoint); accum_host == NULL clears it.
+ * Synchronises the film's stream. */
+int rt_film_upload(rt_film *film, const float *accum_host, int64_t samples);
+
 /* Per-launch timing of the render kernel: between begin and end the library
  * brackets every render-kernel launch of this scene with HIP events on the
  * stream it is launched on; end waits for them and returns the summed

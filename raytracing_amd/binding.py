@@ -18,7 +18,8 @@ LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(os.path.dirname(os.path.
 EXPORTS = ["rt_last_error", "rt_abi_version", "rt_device_count", "rt_camera_initialize",
            "rt_scene_create", "rt_scene_destroy", "rt_scene_get_info", "rt_scene_read_nodes", "rt_trace_batch",
            "rt_trace_batch_device", "rt_render", "rt_render_device", "rt_tonemap_u8", "rt_tonemap_u8_device",
-           "rt_profile_begin", "rt_profile_end", "rt_scene_file_save", "rt_scene_file_load",
+           "rt_film_create", "rt_film_destroy", "rt_film_render", "rt_film_snapshot", "rt_film_wait",
+           "rt_film_upload", "rt_profile_begin", "rt_profile_end", "rt_scene_file_save", "rt_scene_file_load",
            "rt_scene_file_free"]
 
 
@@ -56,6 +57,12 @@ def lib():
                                        C.POINTER(abi.RenderStats)]
         L.rt_tonemap_u8.argtypes = [C.c_void_p, C.c_int64, C.c_float, C.c_void_p]
         L.rt_tonemap_u8_device.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p]
+        L.rt_film_create.argtypes = [C.c_int, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+        L.rt_film_destroy.argtypes = [C.c_void_p]
+        L.rt_film_render.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(abi.CameraDesc), C.POINTER(abi.RenderOpts)]
+        L.rt_film_snapshot.argtypes = [C.c_void_p, C.c_int]
+        L.rt_film_wait.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+        L.rt_film_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.rt_profile_begin.argtypes = [C.c_void_p]
         L.rt_profile_end.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.rt_scene_file_save.argtypes = [C.POINTER(abi.SceneDesc), C.c_char_p]
@@ -160,3 +167,47 @@ class Scene:
         ms, n = C.c_double(), C.c_int()
         check(lib().rt_profile_end(self.handle, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+
+class Film:
+    """Device-resident accumulation image rendered in passes (rt_film_create .. rt_film_destroy)."""
+
+    def __init__(self, width, height, device=0):
+        h = C.c_void_p()
+        check(lib().rt_film_create(device, width, height, C.byref(h)))
+        self.handle, self.width, self.height = h, width, height
+
+    def close(self):
+        if self.handle:
+            lib().rt_film_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def render(self, scene, cam, sample_count, sample_begin, seed=0):
+        o = abi.RenderOpts(sample_begin, sample_count, seed, abi.RT_MODE_MEGAKERNEL, 0)
+        check(lib().rt_film_render(scene.handle, self.handle, C.byref(cam), C.byref(o)))
+
+    def snapshot(self, with_accum=False):
+        check(lib().rt_film_snapshot(self.handle, 1 if with_accum else 0))
+
+    def wait(self, want_accum=False):
+        """Returns (rgb8[H,W,3], accum[H,W,3] or None, samples) of the last snapshot."""
+        rgb = np.zeros((self.height, self.width, 3), np.uint8)
+        acc = np.zeros((self.height, self.width, 3), np.float32) if want_accum else None
+        n = C.c_int64()
+        check(lib().rt_film_wait(self.handle, rgb.ctypes.data, acc.ctypes.data if want_accum else None, C.byref(n)))
+        return rgb, acc, n.value
+
+    def upload(self, accum, samples):
+        if accum is None:
+            check(lib().rt_film_upload(self.handle, None, 0))
+            return
+        accum = np.ascontiguousarray(accum, np.float32)
+        if accum.shape != (self.height, self.width, 3):
+            raise ValueError("accum shape does not match the film")
+        check(lib().rt_film_upload(self.handle, accum.ctypes.data, samples))

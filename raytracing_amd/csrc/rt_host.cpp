@@ -835,6 +835,143 @@ int rt_tonemap_u8_device(int device, const float *d_accum, int64_t n_pixels, flo
     return RT_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// Film: accumulation image resident in HBM, rendered in passes, with asynchronous snapshots.
+struct rt_film {
+    int device = 0, width = 0, height = 0;
+    int64_t samples = 0;      // samples per pixel accumulated (enqueued) so far
+    int64_t snap_samples = 0; // ... at the last snapshot
+    float *d_accum = nullptr;
+    uint8_t *d_rgb = nullptr;
+    uint8_t *h_rgb = nullptr; // pinned
+    float *h_accum = nullptr; // pinned, allocated by the first snapshot that wants the sums
+    hipStream_t stream = nullptr, copy_stream = nullptr;
+    hipEvent_t ev_ready = nullptr, ev_copied = nullptr;
+    bool snap_pending = false, snap_has_accum = false;
+    size_t n_values() const { return (size_t)width * height * 3; }
+};
+
+int rt_film_destroy(rt_film *f) {
+    if (!f) return RT_OK;
+    hipSetDevice(f->device);
+    if (f->stream) hipStreamSynchronize(f->stream);
+    if (f->copy_stream) hipStreamSynchronize(f->copy_stream);
+    if (f->d_accum) hipFree(f->d_accum);
+    if (f->d_rgb) hipFree(f->d_rgb);
+    if (f->h_rgb) hipHostFree(f->h_rgb);
+    if (f->h_accum) hipHostFree(f->h_accum);
+    if (f->ev_ready) hipEventDestroy(f->ev_ready);
+    if (f->ev_copied) hipEventDestroy(f->ev_copied);
+    if (f->stream) hipStreamDestroy(f->stream);
+    if (f->copy_stream) hipStreamDestroy(f->copy_stream);
+    delete f;
+    return RT_OK;
+}
+
+namespace {
+int film_alloc(rt_film *f) {
+    RT_HIP(hipMalloc((void **)&f->d_accum, f->n_values() * sizeof(float)));
+    RT_HIP(hipMalloc((void **)&f->d_rgb, f->n_values()));
+    RT_HIP(hipHostMalloc((void **)&f->h_rgb, f->n_values(), hipHostMallocDefault));
+    RT_HIP(hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking));
+    RT_HIP(hipStreamCreateWithFlags(&f->copy_stream, hipStreamNonBlocking));
+    RT_HIP(hipEventCreateWithFlags(&f->ev_ready, hipEventDisableTiming));
+    RT_HIP(hipEventCreateWithFlags(&f->ev_copied, hipEventDisableTiming));
+    RT_HIP(hipMemsetAsync(f->d_accum, 0, f->n_values() * sizeof(float), f->stream));
+    return RT_OK;
+}
+} // namespace
+
+int rt_film_create(int device, int32_t width, int32_t height, rt_film **out) {
+    if (!out) return fail(RT_ERR_ARG, "out is null");
+    *out = nullptr;
+    if (width <= 0 || height <= 0 || (int64_t)width * height > (1ll << 30))
+        return fail(RT_ERR_ARG, "film size %d x %d", width, height);
+    int n_dev = rt_device_count();
+    if (n_dev <= 0) return fail(RT_ERR_HIP, "no HIP device available (this library has no CPU path)");
+    if (device < 0 || device >= n_dev) return fail(RT_ERR_ARG, "device %d out of range (%d visible)", device, n_dev);
+    int rc = set_device(device);
+    if (rc != RT_OK) return rc;
+    rt_film *f = new rt_film;
+    f->device = device;
+    f->width = width;
+    f->height = height;
+    rc = film_alloc(f);
+    if (rc != RT_OK) {
+        rt_film_destroy(f);
+        return rc;
+    }
+    *out = f;
+    return RT_OK;
+}
+
+int rt_film_render(rt_scene *s, rt_film *f, const rt_camera_desc *cam, const rt_render_opts *opts) {
+    if (!s || !f || !cam || !opts) return fail(RT_ERR_ARG, "null argument");
+    if (s->device != f->device) return fail(RT_ERR_ARG, "scene on device %d, film on device %d", s->device, f->device);
+    rt_camera_frame fr;
+    int rc = rt_camera_initialize(cam, &fr);
+    if (rc != RT_OK) return rc;
+    if (fr.image_width != f->width || fr.image_height != f->height)
+        return fail(RT_ERR_ARG, "camera renders %d x %d, the film is %d x %d", fr.image_width, fr.image_height,
+                    f->width, f->height);
+    rc = rt_render_device(s, cam, opts, f->d_accum, f->stream, nullptr);
+    if (rc != RT_OK) return rc;
+    f->samples += opts->sample_count;
+    return RT_OK;
+}
+
+int rt_film_snapshot(rt_film *f, int with_accum) {
+    if (!f) return fail(RT_ERR_ARG, "null film");
+    if (f->samples <= 0) return fail(RT_ERR_ARG, "the film holds no samples");
+    int rc = set_device(f->device);
+    if (rc != RT_OK) return rc;
+    if (with_accum && !f->h_accum)
+        RT_HIP(hipHostMalloc((void **)&f->h_accum, f->n_values() * sizeof(float), hipHostMallocDefault));
+    // the previous snapshot's copies still read d_rgb
+    if (f->snap_pending) RT_HIP(hipStreamWaitEvent(f->stream, f->ev_copied, 0));
+    RT_HIP(rtl::launch_tonemap(f->d_accum, (long long)f->n_values(), 1.0f / (float)f->samples, f->d_rgb, f->stream));
+    RT_HIP(hipEventRecord(f->ev_ready, f->stream));
+    RT_HIP(hipStreamWaitEvent(f->copy_stream, f->ev_ready, 0));
+    RT_HIP(hipMemcpyAsync(f->h_rgb, f->d_rgb, f->n_values(), hipMemcpyDeviceToHost, f->copy_stream));
+    if (with_accum)
+        RT_HIP(hipMemcpyAsync(f->h_accum, f->d_accum, f->n_values() * sizeof(float), hipMemcpyDeviceToHost, f->copy_stream));
+    RT_HIP(hipEventRecord(f->ev_copied, f->copy_stream));
+    // later passes add to d_accum on f->stream: they wait for the copy of the sums (their render
+    // kernels run on the scene's internal streams and do not)
+    if (with_accum) RT_HIP(hipStreamWaitEvent(f->stream, f->ev_copied, 0));
+    f->snap_pending = true;
+    f->snap_has_accum = with_accum != 0;
+    f->snap_samples = f->samples;
+    return RT_OK;
+}
+
+int rt_film_wait(rt_film *f, uint8_t *rgb8_out, float *accum_out, int64_t *samples_out) {
+    if (!f) return fail(RT_ERR_ARG, "null film");
+    if (!f->snap_pending) return fail(RT_ERR_ARG, "no snapshot was taken");
+    if (accum_out && !f->snap_has_accum) return fail(RT_ERR_ARG, "the snapshot was taken without the sums");
+    int rc = set_device(f->device);
+    if (rc != RT_OK) return rc;
+    RT_HIP(hipEventSynchronize(f->ev_copied));
+    if (rgb8_out) memcpy(rgb8_out, f->h_rgb, f->n_values());
+    if (accum_out) memcpy(accum_out, f->h_accum, f->n_values() * sizeof(float));
+    if (samples_out) *samples_out = f->snap_samples;
+    return RT_OK;
+}
+
+int rt_film_upload(rt_film *f, const float *accum_host, int64_t samples) {
+    if (!f || samples < 0 || (!accum_host && samples != 0)) return fail(RT_ERR_ARG, "bad argument");
+    int rc = set_device(f->device);
+    if (rc != RT_OK) return rc;
+    RT_HIP(hipStreamSynchronize(f->copy_stream));
+    RT_HIP(hipStreamSynchronize(f->stream));
+    if (accum_host)
+        RT_HIP(hipMemcpy(f->d_accum, accum_host, f->n_values() * sizeof(float), hipMemcpyHostToDevice));
+    else
+        RT_HIP(hipMemset(f->d_accum, 0, f->n_values() * sizeof(float)));
+    f->samples = samples;
+    return RT_OK;
+}
+
 // Per-launch timing of the render kernel between begin and end (HIP events on the
 // stream the launches go to).  end returns the summed time and the launch count.
 int rt_profile_begin(rt_scene *s) {

@@ -969,6 +969,16 @@ class camera {
     // Extensions (not in the reference): which GPU renders, and the sampler seed.
     int device = 0;
     uint32_t seed = 0;
+    // Progressive rendering (not in the reference, which writes the image once at the end,
+    // camera.h:56): with pass_samples > 0 the image is accumulated on the GPU in passes of that
+    // many samples per pixel; after every write_every passes the PNG is rewritten from the
+    // samples so far (encoded on the host while the GPU renders the next pass), and with a
+    // checkpoint file the sums are saved beside it, so that a later render() of the same
+    // image continues from there.  Environment overrides: RTAMD_PASS_SPP, RTAMD_WRITE_EVERY,
+    // RTAMD_CHECKPOINT.
+    int pass_samples = 0;
+    int write_every = 1;
+    std::string checkpoint;
 
     rt_camera_desc descriptor() const {
         rt_camera_desc c;
@@ -1015,21 +1025,32 @@ class camera {
         rt_scene *scene = nullptr;
         if (rt_scene_create(&sd, device, 0, &scene) != RT_OK) die("rt_scene_create");
         const int W = frame.image_width, H = frame.image_height;
-        std::vector<float> accum((size_t)W * H * 3, 0.0f);
-        rt_render_opts opts;
-        memset(&opts, 0, sizeof(opts));
-        opts.sample_begin = 0;
-        opts.sample_count = samples_per_pixel;
-        opts.seed = seed;
-        opts.mode = RT_MODE_MEGAKERNEL;
+        int pass = pass_samples, every = write_every;
+        std::string ckpt = checkpoint;
+        if (const char *e = getenv("RTAMD_PASS_SPP")) pass = atoi(e);
+        if (const char *e = getenv("RTAMD_WRITE_EVERY")) every = atoi(e);
+        if (const char *e = getenv("RTAMD_CHECKPOINT")) ckpt = e;
         std::clog << "\rScan lines remaining: " << H << ' ' << std::flush;
         rt_render_stats stats;
-        if (rt_render(scene, &cd, &opts, accum.data(), &stats) != RT_OK) die("rt_render");
-        std::vector<uint8_t> rgb((size_t)W * H * 3);
-        if (rt_tonemap_u8(accum.data(), (int64_t)W * H, frame.pixel_samples_scale, rgb.data()) != RT_OK) die("rt_tonemap_u8");
+        memset(&stats, 0, sizeof(stats));
+        if (pass > 0) {
+            render_in_passes(scene, cd, W, H, pass, every < 1 ? 1 : every, ckpt, file_name);
+        } else {
+            std::vector<float> accum((size_t)W * H * 3, 0.0f);
+            rt_render_opts opts;
+            memset(&opts, 0, sizeof(opts));
+            opts.sample_begin = 0;
+            opts.sample_count = samples_per_pixel;
+            opts.seed = seed;
+            opts.mode = RT_MODE_MEGAKERNEL;
+            if (rt_render(scene, &cd, &opts, accum.data(), &stats) != RT_OK) die("rt_render");
+            std::vector<uint8_t> rgb((size_t)W * H * 3);
+            if (rt_tonemap_u8(accum.data(), (int64_t)W * H, frame.pixel_samples_scale, rgb.data()) != RT_OK)
+                die("rt_tonemap_u8");
+            if (!rtamd::write_png_rgb8(file_name, W, H, rgb.data()))
+                std::cerr << "ERROR: could not write '" << file_name << "'.\n";
+        }
         rt_scene_destroy(scene);
-        if (!rtamd::write_png_rgb8(file_name, W, H, rgb.data()))
-            std::cerr << "ERROR: could not write '" << file_name << "'.\n";
         std::clog << "\rDone.\n";
         double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         std::cerr << "Render took " << seconds << " seconds.\n";
@@ -1037,7 +1058,86 @@ class camera {
     }
     rt_render_stats last_stats = {};
 
+    // Checkpoint file of a progressive render: "RTACCUM1", width, height (int32), samples
+    // (int64), seed (uint32), 0 (uint32), then width*height*3 floats (radiance sums).
+    static bool save_checkpoint(const std::string &path, int W, int H, int64_t samples, uint32_t seed,
+                                const float *accum) {
+        std::string tmp = path + ".tmp";
+        FILE *f = fopen(tmp.c_str(), "wb");
+        if (!f) return false;
+        int32_t wh[2] = {W, H};
+        uint32_t tail[2] = {seed, 0u};
+        bool ok = fwrite("RTACCUM1", 1, 8, f) == 8 && fwrite(wh, 4, 2, f) == 2 && fwrite(&samples, 8, 1, f) == 1 &&
+                  fwrite(tail, 4, 2, f) == 2 && fwrite(accum, sizeof(float), (size_t)W * H * 3, f) == (size_t)W * H * 3;
+        ok = fclose(f) == 0 && ok;
+        return ok && rename(tmp.c_str(), path.c_str()) == 0; // a reader never sees half a file
+    }
+    static bool load_checkpoint(const std::string &path, int W, int H, uint32_t seed, int64_t &samples,
+                                std::vector<float> &accum) {
+        FILE *f = fopen(path.c_str(), "rb");
+        if (!f) return false;
+        char magic[8];
+        int32_t wh[2];
+        uint32_t tail[2];
+        accum.resize((size_t)W * H * 3);
+        bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, "RTACCUM1", 8) == 0 && fread(wh, 4, 2, f) == 2 &&
+                  wh[0] == W && wh[1] == H && fread(&samples, 8, 1, f) == 1 && fread(tail, 4, 2, f) == 2 &&
+                  tail[0] == seed && samples >= 0 &&
+                  fread(accum.data(), sizeof(float), accum.size(), f) == accum.size();
+        fclose(f);
+        return ok;
+    }
+
   private:
+    void render_in_passes(rt_scene *scene, const rt_camera_desc &cd, int W, int H, int pass, int every,
+                          const std::string &ckpt, const char *file_name) {
+        rt_film *film = nullptr;
+        if (rt_film_create(device, W, H, &film) != RT_OK) die("rt_film_create");
+        int64_t done = 0;
+        std::vector<float> sums;
+        if (!ckpt.empty() && load_checkpoint(ckpt, W, H, seed, done, sums) && done <= samples_per_pixel) {
+            if (rt_film_upload(film, sums.data(), done) != RT_OK) die("rt_film_upload");
+            std::clog << "\rResuming at sample " << done << " of " << samples_per_pixel << ".\n";
+        } else {
+            done = 0;
+        }
+        std::vector<uint8_t> rgb((size_t)W * H * 3);
+        if (!ckpt.empty()) sums.resize((size_t)W * H * 3);
+        bool pending = false;
+        // what the host does with a finished snapshot, while the GPU renders on
+        auto finish_snapshot = [&]() {
+            int64_t n = 0;
+            if (rt_film_wait(film, rgb.data(), ckpt.empty() ? nullptr : sums.data(), &n) != RT_OK) die("rt_film_wait");
+            if (!rtamd::write_png_rgb8(file_name, W, H, rgb.data()))
+                std::cerr << "ERROR: could not write '" << file_name << "'.\n";
+            if (!ckpt.empty() && !save_checkpoint(ckpt, W, H, n, seed, sums.data()))
+                std::cerr << "ERROR: could not write '" << ckpt << "'.\n";
+            std::clog << "\rSamples per pixel done: " << n << " of " << samples_per_pixel << ' ' << std::flush;
+            pending = false;
+        };
+        if (done >= samples_per_pixel && done > 0) { // nothing left to render: rewrite the image
+            if (rt_film_snapshot(film, ckpt.empty() ? 0 : 1) != RT_OK) die("rt_film_snapshot");
+            pending = true;
+        }
+        for (int k = 1; done < samples_per_pixel; k++) {
+            rt_render_opts opts;
+            memset(&opts, 0, sizeof(opts));
+            opts.sample_begin = (int32_t)done;
+            opts.sample_count = (int32_t)std::min<int64_t>(pass, samples_per_pixel - done);
+            opts.seed = seed;
+            opts.mode = RT_MODE_MEGAKERNEL;
+            if (rt_film_render(scene, film, &cd, &opts) != RT_OK) die("rt_film_render");
+            done += opts.sample_count;
+            if (pending) finish_snapshot(); // the previous snapshot, beside the pass just enqueued
+            if (k % every == 0 || done >= samples_per_pixel) {
+                if (rt_film_snapshot(film, ckpt.empty() ? 0 : 1) != RT_OK) die("rt_film_snapshot");
+                pending = true;
+            }
+        }
+        if (pending) finish_snapshot();
+        rt_film_destroy(film);
+    }
+
     [[noreturn]] static void die(const char *what) {
         std::cerr << "rtamd: " << what << " failed: " << rt_last_error() << "\n";
         exit(1);
