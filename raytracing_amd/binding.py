@@ -57,12 +57,13 @@ def lib():
                                        C.POINTER(abi.RenderStats)]
         L.rt_tonemap_u8.argtypes = [C.c_void_p, C.c_int64, C.c_float, C.c_void_p]
         L.rt_tonemap_u8_device.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p]
-        L.rt_film_create.argtypes = [C.c_int, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
-        L.rt_film_destroy.argtypes = [C.c_void_p]
-        L.rt_film_render.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(abi.CameraDesc), C.POINTER(abi.RenderOpts)]
-        L.rt_film_snapshot.argtypes = [C.c_void_p, C.c_int]
-        L.rt_film_wait.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
-        L.rt_film_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        if hasattr(L, "rt_film_create"):  # (older builds of the library, loaded through RT_AMD_LIB for A/B runs, lack it)
+            L.rt_film_create.argtypes = [C.c_int, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+            L.rt_film_destroy.argtypes = [C.c_void_p]
+            L.rt_film_render.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(abi.CameraDesc), C.POINTER(abi.RenderOpts)]
+            L.rt_film_snapshot.argtypes = [C.c_void_p, C.c_int]
+            L.rt_film_wait.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+            L.rt_film_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.rt_profile_begin.argtypes = [C.c_void_p]
         L.rt_profile_end.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.rt_scene_file_save.argtypes = [C.POINTER(abi.SceneDesc), C.c_char_p]

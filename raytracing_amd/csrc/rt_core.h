@@ -124,6 +124,7 @@ struct DevScene {
     int n_chains;
     int n_xf_ops;
     int lds_records; // LDS staging also covers rec_i / rec_f / textures (else only slots + nodes)
+    int n_top;       // scenes that stay in HBM: nodes [0, n_top) are also kept in LDS (the top of the tree)
 };
 
 // The five hot arrays, wherever they currently live (HBM or this workgroup's LDS).
@@ -133,6 +134,8 @@ struct SceneView {
     const i4 *rec_i;
     const f4 *rec_f;
     const rt_texture *textures;
+    const f4 *top; // LDS copy of nodes [0, n_top) when the scene itself stays in HBM
+    int n_top;
 };
 RT_HD SceneView global_view(const DevScene &sc) {
     SceneView v;
@@ -141,6 +144,8 @@ RT_HD SceneView global_view(const DevScene &sc) {
     v.rec_i = sc.rec_i;
     v.rec_f = sc.rec_f;
     v.textures = sc.textures;
+    v.top = nullptr;
+    v.n_top = 0;
     return v;
 }
 
@@ -488,10 +493,18 @@ template <typename StackT> RT_HD void trav_pop(Trav &tv, const StackT *stack, in
 }
 // One inner node (requires tv.ref >= 0): tests both children, descends into the
 // nearer one that is hit and pushes the other.
-template <bool COUNT, typename StackT>
-RT_HD void trav_inner(Trav &tv, const f4 *nodes, float tmin, StackT *stack, int stack_stride, Cnt<COUNT> &cn) {
-    const f4 *n = nodes + (size_t)tv.ref * 4;
-    f4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+// TOP: nodes [0, n_top) are read from `top` (the workgroup's LDS) instead of `nodes` (HBM).
+template <bool COUNT, typename StackT, bool TOP = false>
+RT_HD void trav_inner(Trav &tv, const f4 *nodes, float tmin, StackT *stack, int stack_stride, Cnt<COUNT> &cn,
+                      const f4 *top = nullptr, int n_top = 0) {
+    f4 n0, n1, n2, n3;
+    if (TOP && tv.ref < n_top) { // two explicit paths: LDS reads and global loads, no flat addressing
+        const f4 *n = top + (size_t)tv.ref * 4;
+        n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+    } else {
+        const f4 *n = nodes + (size_t)tv.ref * 4;
+        n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+    }
     if constexpr (COUNT) cn.box += 2;
     float e0, e1;
     bool h0 = box_hit(mk(n0.x, n0.y, n0.z), mk(n0.w, n1.x, n1.y), tv.br, tmin, tv.best_t, e0);

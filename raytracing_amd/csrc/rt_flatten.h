@@ -22,6 +22,8 @@ using rtc::mk;
 
 const int kLinearMaxPrims = 32;       // at most this many primitives: scan, no tree
 const int kMaxLdsBytes = 160 * 1024;  // LDS per CU on gfx950
+const int kTreeTopMin = 2560;         // trees of at least this many 64-byte nodes never fit LDS whole
+const int kTreeTopMax = 2048;         // nodes moved to the front for the LDS copy of the tree's top
 const int kMaxInnerDepth = RT_STACK_DEPTH - 2;
 
 // ---------------------------------------------------------------------------------------
@@ -137,6 +139,54 @@ inline void center_half(const Box3 &b, float *c, float *h) {
         c[k] = cf;
         h[k] = hf;
     }
+}
+
+// Moves the most visited part of a tree to the front of the node array, so that a kernel
+// can keep a prefix of it in LDS while the rest stays in HBM.  Nodes are picked greedily by
+// the surface area of their box (the chance that a random ray visits them), starting at the
+// root; every prefix of the new order is a connected top of the tree.  The remaining nodes
+// keep their relative order.  Returns the number of nodes picked (at most max_top).
+inline int reorder_tree_top(std::vector<f4> &nodes, int max_top) {
+    const int n = (int)(nodes.size() / 4);
+    if (n <= 1 || max_top <= 0) return n <= 1 ? n : 0;
+    auto child_ref = [&](int node, int k) { return __builtin_bit_cast(int, k == 0 ? nodes[(size_t)node * 4 + 3].x : nodes[(size_t)node * 4 + 3].y); };
+    auto child_area = [&](int node, int k) {
+        const f4 *q = &nodes[(size_t)node * 4];
+        float hx = k == 0 ? q[0].w : q[2].y, hy = k == 0 ? q[1].x : q[2].z, hz = k == 0 ? q[1].y : q[2].w;
+        return hx * hy + hy * hz + hz * hx;
+    };
+    std::vector<int> picked;
+    std::vector<std::pair<float, int>> heap; // (area, node)
+    picked.reserve(max_top);
+    heap.push_back({INFINITY, 0});
+    while (!heap.empty() && (int)picked.size() < max_top) {
+        std::pop_heap(heap.begin(), heap.end());
+        int node = heap.back().second;
+        heap.pop_back();
+        picked.push_back(node);
+        for (int k = 0; k < 2; k++) {
+            int r = child_ref(node, k);
+            if (r >= 0) {
+                heap.push_back({child_area(node, k), r});
+                std::push_heap(heap.begin(), heap.end());
+            }
+        }
+    }
+    std::vector<int> new_index(n, -1);
+    for (size_t i = 0; i < picked.size(); i++) new_index[picked[i]] = (int)i;
+    int next = (int)picked.size();
+    for (int i = 0; i < n; i++)
+        if (new_index[i] < 0) new_index[i] = next++;
+    std::vector<f4> out(nodes.size());
+    for (int i = 0; i < n; i++) {
+        f4 *q = &out[(size_t)new_index[i] * 4];
+        memcpy(q, &nodes[(size_t)i * 4], 4 * sizeof(f4));
+        int r0 = __builtin_bit_cast(int, q[3].x), r1 = __builtin_bit_cast(int, q[3].y);
+        if (r0 >= 0) q[3].x = __builtin_bit_cast(float, new_index[r0]);
+        if (r1 >= 0) q[3].y = __builtin_bit_cast(float, new_index[r1]);
+    }
+    nodes.swap(out);
+    return (int)picked.size();
 }
 
 // ---------------------------------------------------------------------------------------
@@ -309,6 +359,7 @@ struct HostScene {
     int slot_f4 = 2;
     int n_prims = 0, n_spheres = 0, n_quads = 0;
     int n_nodes = 0, bvh_depth = 0;
+    int n_top = 0; // nodes [0, n_top) are the most visited ones (reorder_tree_top); 0: order as built
     bool linear = true;
     bool any_chain = false; // some primitive sits inside instance wrappers
     bool external_nodes = false; // the nodes were built (and are kept) by the external builder
@@ -425,6 +476,8 @@ inline int flatten_scene(const rt_scene_desc *d, uint32_t flags, HostScene &out,
         }
         out.external_nodes = built;
         nodes = std::move(bo.nodes);
+        // trees too large for LDS: their top is cached there (kTreeTopMin nodes is more than a CU's LDS holds)
+        out.n_top = (!built && bo.n_nodes >= kTreeTopMin) ? reorder_tree_top(nodes, kTreeTopMax) : 0;
         slots.resize((size_t)n * slot_f4);
         for (int sl = 0; sl < n; sl++) {
             int pi = bo.leaf_order[sl];

@@ -77,6 +77,7 @@ struct rt_scene {
     unsigned long long *d_words = nullptr; // [0] pool counter, [1] ray counter
     rtc::Counters *d_counters = nullptr;
     int n_cu = 256;
+    int tree_top = 0; // HostScene::n_top: how many leading nodes are the most visited ones
     bool lean = false; // no quads, no noise / image textures: the lean render kernels apply
     LaunchGeom geom; // persistent render kernel: grid, block, LDS bytes, what is staged
     LaunchGeom pool_geom; // the same for render_pool_bvh (pool_slots = 0: not available)
@@ -204,10 +205,17 @@ LaunchGeom choose_geom(rt_scene *s, uint32_t flags) {
             if (lg.lds_scene) break;
         }
     }
-    if (!lg.lds_scene) { // geometry stays in HBM; only the 32-bit stacks use LDS
+    dv.n_top = 0;
+    if (!lg.lds_scene) { // geometry stays in HBM; LDS holds the 32-bit stacks and the top of the tree
         size_t stack = bvh ? (size_t)levels * block * sizeof(int) : 0;
         bpc = std::max(1, std::min(bpc_target, (int)(kMaxLdsBytes / std::max<size_t>(stack, 1))));
         lg.lds_bytes = (int)stack;
+        if (bvh && s->tree_top > 0 && env_int("RT_AMD_TREE_TOP", 1) != 0) {
+            size_t room = (size_t)kMaxLdsBytes / bpc > stack ? (size_t)kMaxLdsBytes / bpc - stack : 0;
+            dv.n_top = (int)std::min<size_t>((size_t)s->tree_top, room / (4 * sizeof(f4)));
+            dv.n_top = std::min(dv.n_top, std::max(0, env_int("RT_AMD_TREE_TOP_NODES", dv.n_top)));
+            lg.lds_bytes += dv.n_top * 4 * (int)sizeof(f4);
+        }
     }
     lg.lds_bytes = std::max(lg.lds_bytes, 16);
     lg.grid = s->n_cu * std::max(bpc, 1);
@@ -421,6 +429,8 @@ int rt_scene_create(const rt_scene_desc *d, int device, uint32_t flags, rt_scene
     s->d_counters = const_cast<rtc::Counters *>(dc);
     dv.n_slots = n;
     dv.n_nodes = hs.n_nodes;
+    dv.n_top = 0; // chosen with the launch geometry
+    s->tree_top = hs.n_top;
     dv.n_textures = (int)texs.size();
     dv.slot_f4 = slot_f4;
     dv.traversal = linear ? rtc::TRAV_LINEAR : rtc::TRAV_BVH;
@@ -638,6 +648,7 @@ int rt_render_device(rt_scene *s, const rt_camera_desc *cam, const rt_render_opt
         rp.seed = opts->seed;
         rp.n_strips = (unsigned)((n_pixels + 63) / 64);
         rp.n_units = rp.n_strips * (unsigned)sc_n;
+        rp.pixel_major = env_int("RT_AMD_UNIT_ORDER", 1);
         rp.stage = s->stage[b];
         rp.next_chunk = reinterpret_cast<unsigned *>(s->d_words + 2 * b); // words 0 / 2: pool counters, 1: rays
         rp.counters = count ? s->d_counters : nullptr;

@@ -155,8 +155,14 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
     SceneView vw = global_view(sc);
     f4 *free_lds = smem;
     if constexpr (LDS_SCENE) free_lds = stage_scene(sc, smem, vw);
-    else __syncthreads();
     using StackT = typename std::conditional<LDS_SCENE, short, int>::type;
+    if constexpr (!LDS_SCENE) { // the scene stays in HBM: the top of the tree comes along
+        stage_to_lds(free_lds, sc.nodes, sc.n_top * 4);
+        vw.top = free_lds;
+        vw.n_top = sc.n_top;
+        free_lds += (size_t)sc.n_top * 4;
+        __syncthreads();
+    }
     StackT *stack = reinterpret_cast<StackT *>(free_lds) + threadIdx.x;
     const int stack_stride = blockDim.x;
 
@@ -354,7 +360,8 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
             // below cost about as much as a node step, so they are amortised.
 #pragma unroll
             for (int k = 0; k < RT_INNER_UNROLL; k++) {
-                if (trav && tv.ref >= 0) trav_inner<COUNT, StackT>(tv, vw.nodes, 0.001f, stack, stack_stride, cn);
+                if (trav && tv.ref >= 0)
+                    trav_inner<COUNT, StackT, !LDS_SCENE>(tv, vw.nodes, 0.001f, stack, stack_stride, cn, vw.top, vw.n_top);
                 // A leaf does not stop the lane: it is parked in the lane's pending slot and the
                 // traversal goes on; parked leaves are tested together once enough lanes hold one.
                 if (trav && tv.ref < 0 && tv.ref != RT_TRAV_DONE && pend == 0) {

@@ -29,6 +29,7 @@ struct RenderParams {
     uint32_t seed;
     unsigned n_strips;             // ceil(n_pixels / 64)
     unsigned n_units;              // n_strips * sample_count: units of 64 paths (rt_wavepool.h)
+    int pixel_major;               // order of the units: 0 sample-major, 1 pixel-major
     rtc::f4 *stage;                // [sample_count][n_pixels] {r g b rays}
     unsigned *next_chunk;          // pool counter, zeroed before the launch
     rtc::Counters *counters;       // non-null: count tests (instrumented kernel variant)

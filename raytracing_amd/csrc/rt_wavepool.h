@@ -29,7 +29,9 @@ template <bool COUNT> __device__ __forceinline__ void flush_counters(Counters *o
 }
 
 // Pool of paths.  The launch is a sequence of units of 64 paths: unit u covers the pixels
-// [64 * (u % n_strips), +64) of local sample u / n_strips.  Two levels:
+// [64 * (u % n_strips), +64) of local sample u / n_strips (sample-major), or the pixels
+// [64 * (u / sample_count), +64) of local sample u % sample_count (RenderParams::pixel_major:
+// scenes read from HBM, where the waves of a CU should work on neighbouring rays).  Two levels:
 //   * the workgroup reserves runs of consecutive units from the launch's global counter, one
 //     atomic per run, and fewer units per run as the launch runs out ("guided" self-scheduling:
 //     few atomics on the one hot counter while there is plenty of work — every access to it is
@@ -128,8 +130,14 @@ __device__ __forceinline__ void pool_refill(WavePool &wp, BlockPool *bp, const R
         wp.exhausted = true;
         return;
     }
-    const unsigned s0 = unit / rp.n_strips;
-    const unsigned strip0 = unit - s0 * rp.n_strips;
+    unsigned s0, strip0;
+    if (rp.pixel_major) { // all samples of a strip in a row: the rays of a workgroup stay together
+        strip0 = unit / (unsigned)rp.sample_count;
+        s0 = unit - strip0 * (unsigned)rp.sample_count;
+    } else {
+        s0 = unit / rp.n_strips;
+        strip0 = unit - s0 * rp.n_strips;
+    }
     wp.s_base = s0;
     wp.k = 0;
     wp.k_end = 64u;

@@ -149,6 +149,33 @@ def test_synth_full_grid(tmp_path):
     sc.close()
 
 
+def test_tree_top_in_lds_changes_nothing(tmp_path, monkeypatch):
+    """Scenes that stay in HBM keep the most visited nodes of their tree in LDS as well: same
+    tree (node order aside), same closest hits, same image bit for bit as without the copy."""
+    B = _binding()
+    arrays, cam = _synth(tmp_path, 60)
+    cam.image_width = 320
+    rng = np.random.default_rng(11)
+    rays = _camera_rays(cam, 3000, rng)
+    sc = B.Scene(arrays)
+    info = sc.info()
+    assert info.lds_resident == 0
+    depth, inner, leaves, outside = _tree_stats(sc.nodes())
+    assert inner == info.n_nodes and leaves == len(arrays.prims) and depth == info.bvh_depth and outside == 0
+    hits = sc.trace(rays)
+    a, st = sc.render(cam, 6, seed=4)
+    sc.close()
+    for knob, value in (("RT_AMD_TREE_TOP", "0"), ("RT_AMD_TREE_TOP_NODES", "37")):
+        monkeypatch.setenv(knob, value)
+        sc = B.Scene(arrays)
+        h0 = sc.trace(rays)
+        b, st0 = sc.render(cam, 6, seed=4)
+        sc.close()
+        monkeypatch.delenv(knob)
+        assert np.array_equal(hits["prim"], h0["prim"]) and np.array_equal(hits["t"], h0["t"])
+        assert st.rays == st0.rays and np.array_equal(a, b)
+
+
 def _tree_stats(nodes):
     """Walks a BVH read back with rt_scene_read_nodes: inner levels, inner nodes reached, distinct
     leaf slots, child boxes that stick out of their parent's box."""
