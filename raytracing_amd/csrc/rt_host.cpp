@@ -357,6 +357,7 @@ int rt_scene_create(const rt_scene_desc *d, int device, uint32_t flags, rt_scene
                 bo.n_nodes = np - 1;
                 return true;
             };
+        if (env_int("RT_AMD_FORCE_BVH", 0)) flags |= RT_SCENE_FORCE_BVH; // experiments: a tree for small scenes too
         rc = rtf::flatten_scene(d, flags, hs, err, device_builder);
         if (rc != RT_OK) {
             if (d_built_nodes) hipFree(d_built_nodes);
@@ -553,6 +554,10 @@ int rt_render_device(rt_scene *s, const rt_camera_desc *cam, const rt_render_opt
     // samples per launch: the per-path record buffer is bounded
     size_t per_sample = (size_t)n_pixels * sizeof(f4);
     int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)opts->sample_count, stage_budget_bytes() / per_sample));
+    {   // launches of equal size: a short last launch pays the same tail as a long one
+        const int n_launches = (opts->sample_count + chunk - 1) / chunk;
+        chunk = (opts->sample_count + n_launches - 1) / n_launches;
+    }
     size_t need = per_sample * chunk;
     auto ensure_stage = [&](int b) -> int {
         if (need > s->stage_bytes[b]) {
