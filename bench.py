@@ -103,8 +103,8 @@ def cpu_baseline(scene, budget_paths):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--scene", default="bouncing_spheres")
     ap.add_argument("--spp", type=int, default=100, help="samples per pixel per step per GPU")
     ap.add_argument("--width", type=int, default=0, help="override image width (0: the scene's own)")
@@ -122,8 +122,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # under torch.distributed.run the collectives run even with one rank (same code path as N > 1)
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world)
     if args.gpus != world and rank == 0:
         print(f"[bench] --gpus {args.gpus} but WORLD_SIZE {world}: using {world}", file=sys.stderr)
@@ -157,14 +160,14 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     scene.profile_begin()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms, n_launches = scene.profile_end()
@@ -178,7 +181,7 @@ def main():
         torch.cuda.synchronize()
         iso_ms, iso_launches = scene.profile_end()
 
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -230,7 +233,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.scene, args.cpu_paths)
         print(json.dumps(out))
     scene.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
