@@ -202,6 +202,12 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
 #define RT_TICK() if constexpr (COUNT) c_mark = clock64()
 #define RT_TOCK(acc) if constexpr (COUNT) acc += clock64() - c_mark
 
+    // The wave's loop exists twice: the first copy runs while the launch still has new paths to
+    // hand out and contains nothing of the tail hand-over (its registers and branches cost the
+    // main phase a few per cent of VALU instructions even when they do nothing); the second copy
+    // takes over when the pool has run dry, and contains no code that starts paths.
+    auto run_phase = [&](auto tail_tag) {
+    constexpr bool TAIL = decltype(tail_tag)::value;
     for (;;) {
         if constexpr (COUNT) {
             if (w_dry == 0 && wp.exhausted && wp.k >= wp.k_end) w_dry = wall_clock64();
@@ -230,10 +236,10 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
         RT_TOCK(c_shade);
         RT_TICK();
         // ---- hand new paths to idle lanes -------------------------------------------------------
-        unsigned long long need = __ballot(state == ST_IDLE);
+        unsigned long long need = TAIL ? 0ull : __ballot(state == ST_IDLE);
         // starting paths (camera ray, sampler seed) is batched like everything else: wait
         // until regen_min lanes are idle unless nothing else is left to do
-        if (need != 0ull && (__popcll(need) >= regen_min || !__any(state == ST_TRAV))) {
+        if (!TAIL && need != 0ull && (__popcll(need) >= regen_min || !__any(state == ST_TRAV))) {
             // the idle lanes take consecutive paths; a unit that runs out half-way is followed
             // by the next one at once, so that all of them start together below
             bool want = state == ST_IDLE, start = false;
@@ -264,9 +270,11 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
             }
         }
         RT_TOCK(c_regen);
-        const bool pool_dry = wp.exhausted && wp.k >= wp.k_end;
-        if (timeline && tl_dry == 0ull && pool_dry) tl_dry = wall_clock64();
-        if (spill_max > 0 && pool_dry) {
+        const bool pool_dry = TAIL || (wp.exhausted && wp.k >= wp.k_end);
+        if constexpr (!TAIL) {
+            if (pool_dry) return; // on to the tail copy of the loop
+        }
+        if (TAIL && spill_max > 0) {
             if (!is_server) {
                 // ---- producer: down to a few paths, hand them over and leave ------------------------
                 unsigned long long live = __ballot(state == ST_TRAV);
@@ -396,6 +404,10 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
             if (trav && tv.ref == RT_TRAV_DONE && pend == 0) state = ST_READY;
         }
     }
+    };
+    run_phase(std::false_type{});
+    if (timeline) tl_dry = wall_clock64();
+    run_phase(std::true_type{});
     if (timeline && lane == 0) {
         unsigned long long *t = rp.timeline + 4u * ((size_t)blockIdx.x * waves_per_block + (threadIdx.x >> 6));
         t[0] = tl_start;
