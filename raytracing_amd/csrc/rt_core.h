@@ -452,9 +452,11 @@ RT_HD bool box_hit(f3 c, f3 h, const BoxRay &b, float tmin, float tmax, float &t
     float nz = __builtin_fmaf(-h.z, iz, mz), fz = __builtin_fmaf(h.z, iz, mz);
     tn = fmaxf(fmaxf(nx, ny), fmaxf(nz, tmin));
     float tf = fminf(fminf(fx, fy), fminf(fz, tmax));
-    // exit parameter widened by the absolute slack (2e) and a relative one (2^-19 |tf|) for the
-    // rounding of the fma results themselves; when the test is close, |tn| ~ |tf|
-    float tf_wide = __builtin_fmaf(1.9073486328125e-6f, fabsf(tf), tf + b.e2);
+    // exit parameter widened by the absolute slack (2e) and a relative one (2^-19 tf) for the
+    // rounding of the fma results themselves; when the test is close, |tn| ~ |tf|.  One FMA:
+    // for tf < 0 the relative part narrows instead, by less than 2^-19 * tmin where it could
+    // matter (tn >= tmin > 0 rejects anything whose widened exit stays below tmin)
+    float tf_wide = __builtin_fmaf(tf, 1.0f + 1.9073486328125e-6f, b.e2);
     return tn <= tf_wide;
 }
 
