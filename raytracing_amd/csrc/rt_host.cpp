@@ -190,6 +190,12 @@ LaunchGeom choose_geom(rt_scene *s, uint32_t flags) {
     lg.lds_records = 0;
     lg.pool_slots = 0;
     int bpc = bpc_target;
+    // the decoupled kernel's camera-ray rings (one per wave) come after the stacks if there is room
+    const size_t ring_bytes = bvh && env_int("RT_AMD_RING", 1) != 0
+                                  ? (size_t)(block / 64) * RT_RING_F4_PER_WAVE * sizeof(f4) : 0;
+    lg.ring = false;
+    lg.ring_f4 = 0;
+    size_t used = 0; // scene copy / tree top + stacks: where the rings start
     if (!(flags & RT_SCENE_FORCE_GLOBAL) && short_ok) {
         for (bpc = bpc_target; bpc >= 1 && !lg.lds_scene; bpc--) {
             size_t budget = (size_t)kMaxLdsBytes / bpc;
@@ -197,26 +203,40 @@ LaunchGeom choose_geom(rt_scene *s, uint32_t flags) {
             if (all_bytes + stack <= budget) {
                 lg.lds_scene = true;
                 lg.lds_records = 1;
-                lg.lds_bytes = (int)(all_bytes + stack);
+                used = all_bytes + stack;
+                // the rings are worth more than the records in LDS (the records are read once per hit)
+                if (ring_bytes && used + ring_bytes > budget && geom_bytes + stack + ring_bytes <= budget) {
+                    lg.lds_records = 0;
+                    used = geom_bytes + stack;
+                }
             } else if (geom_bytes + stack <= budget) {
                 lg.lds_scene = true;
-                lg.lds_bytes = (int)(geom_bytes + stack);
+                used = geom_bytes + stack;
             }
-            if (lg.lds_scene) break;
+            if (lg.lds_scene) {
+                lg.ring = ring_bytes && used + ring_bytes <= budget;
+                break;
+            }
         }
     }
     dv.n_top = 0;
-    if (!lg.lds_scene) { // geometry stays in HBM; LDS holds the 32-bit stacks and the top of the tree
+    if (!lg.lds_scene) { // geometry stays in HBM; LDS holds the 32-bit stacks, the rings and the top of the tree
         size_t stack = bvh ? (size_t)levels * block * sizeof(int) : 0;
-        bpc = std::max(1, std::min(bpc_target, (int)(kMaxLdsBytes / std::max<size_t>(stack, 1))));
-        lg.lds_bytes = (int)stack;
+        bpc = std::max(1, std::min(bpc_target, (int)(kMaxLdsBytes / std::max<size_t>(stack + ring_bytes, 1))));
+        size_t budget = (size_t)kMaxLdsBytes / bpc;
+        lg.ring = ring_bytes && stack + ring_bytes <= budget;
+        used = stack;
         if (bvh && s->tree_top > 0 && env_int("RT_AMD_TREE_TOP", 1) != 0) {
-            size_t room = (size_t)kMaxLdsBytes / bpc > stack ? (size_t)kMaxLdsBytes / bpc - stack : 0;
+            size_t taken = stack + (lg.ring ? ring_bytes : 0);
+            size_t room = budget > taken ? budget - taken : 0;
             dv.n_top = (int)std::min<size_t>((size_t)s->tree_top, room / (4 * sizeof(f4)));
             dv.n_top = std::min(dv.n_top, std::max(0, env_int("RT_AMD_TREE_TOP_NODES", dv.n_top)));
-            lg.lds_bytes += dv.n_top * 4 * (int)sizeof(f4);
+            used += (size_t)dv.n_top * 4 * sizeof(f4);
         }
     }
+    used = (used + 15) / 16 * 16;
+    lg.ring_f4 = (int)(used / sizeof(f4));
+    lg.lds_bytes = (int)(used + (lg.ring ? ring_bytes : 0));
     lg.lds_bytes = std::max(lg.lds_bytes, 16);
     lg.grid = s->n_cu * std::max(bpc, 1);
     return lg;
@@ -654,6 +674,7 @@ int rt_render_device(rt_scene *s, const rt_camera_desc *cam, const rt_render_opt
         rp.n_strips = (unsigned)((n_pixels + 63) / 64);
         rp.n_units = rp.n_strips * (unsigned)sc_n;
         rp.pixel_major = env_int("RT_AMD_UNIT_ORDER", 1);
+        rp.ring_f4 = lg.ring_f4;
         rp.stage = s->stage[b];
         rp.next_chunk = reinterpret_cast<unsigned *>(s->d_words + 2 * b); // words 0 / 2: pool counters, 1: rays
         rp.counters = count ? s->d_counters : nullptr;

@@ -146,7 +146,7 @@ render_mega(DevScene sc, DevCamera cam, RenderParams rp) {
 
 // ------------------------------------------------------------------------------------------
 // BVH scenes: traversal and shading are decoupled (see the header comment).
-template <bool LDS_SCENE, bool COUNT>
+template <bool LDS_SCENE, bool COUNT, bool RING>
 __global__ void __launch_bounds__(RT_MEGA_MAX_THREADS, RT_MEGA_WAVES_PER_SIMD)
 render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
     extern __shared__ f4 smem[];
@@ -165,6 +165,8 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
     }
     StackT *stack = reinterpret_cast<StackT *>(free_lds) + threadIdx.x;
     const int stack_stride = blockDim.x;
+    // RING: the camera rays of the wave's current unit, structure of arrays over its 64 paths
+    f4 *ring = RING ? smem + rp.ring_f4 + (size_t)(threadIdx.x >> 6) * RT_RING_F4_PER_WAVE : nullptr;
 
     const int lane = threadIdx.x & 63;
     const unsigned long long lane_mask_lt = (1ull << lane) - 1ull;
@@ -219,6 +221,7 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
         }
         // ---- shade the lanes whose closest hit is known ---------------------------------------
         RT_TICK();
+        bool begin = false; // the lane has a new ray: scattered here, or a camera ray below
         if (state == ST_READY) {
             TraceHit h;
             h.t = tv.best_t;
@@ -226,7 +229,7 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
             bool cont = path_after_trace<COUNT>(sc, vw, cam, ps, h, cn);
             if (cont) {
                 n_rays++;
-                trav_begin(tv, ps.ray, RT_INF);
+                begin = true;
                 state = ST_TRAV;
             } else {
                 write_record(rp, sample, pixel, ps.L, n_rays);
@@ -245,30 +248,63 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
             bool want = state == ST_IDLE, start = false;
             int px = 0, py = 0;
             for (int pass = 0; pass < 2 && need != 0ull; pass++) {
-                pool_refill(wp, &block_pool, rp, lane);
+                const bool new_unit = pool_refill(wp, &block_pool, rp, lane);
                 if (!(wp.k < wp.k_end)) break;
+                if constexpr (RING) {
+                    if (new_unit) {
+                        // all 64 camera rays of the unit at once, with every lane (starting a handful
+                        // of paths at a time costs the same instructions for a few lanes each time)
+                        unsigned g_pixel, g_sample;
+                        int gx, gy;
+                        const bool valid = pool_decode(wp, rp, (unsigned)lane, g_pixel, g_sample, gx, gy);
+                        const PathState g = path_start(cam, rp.seed, g_pixel, gx, gy, (unsigned)rp.sample_begin + g_sample);
+                        ring[lane] = f4{g.ray.o.x, g.ray.o.y, g.ray.o.z, g.ray.tm};
+                        ring[64 + lane] = f4{g.ray.d.x, g.ray.d.y, g.ray.d.z, __builtin_bit_cast(float, g.rng.s)};
+                        ring[128 + lane] = f4{__builtin_bit_cast(float, valid ? g_pixel : ~0u),
+                                              __builtin_bit_cast(float, g_sample), 0.0f, 0.0f};
+                    }
+                }
                 const unsigned avail = wp.k_end - wp.k;
                 const unsigned n_need = (unsigned)__popcll(need);
                 const unsigned r = (unsigned)__popcll(need & lane_mask_lt);
                 const bool mine = want && r < avail;
                 if (mine) {
-                    start = pool_decode(wp, rp, wp.k + r, pixel, sample, px, py);
+                    if constexpr (RING) {
+                        const f4 a0 = ring[wp.k + r], a1 = ring[64 + wp.k + r], a2 = ring[128 + wp.k + r];
+                        pixel = __builtin_bit_cast(unsigned, a2.x);
+                        sample = __builtin_bit_cast(unsigned, a2.y);
+                        start = pixel != ~0u;
+                        ps.ray.o = mk(a0.x, a0.y, a0.z);
+                        ps.ray.tm = a0.w;
+                        ps.ray.d = mk(a1.x, a1.y, a1.z);
+                        ps.rng.s = __builtin_bit_cast(unsigned, a1.w);
+                    } else {
+                        start = pool_decode(wp, rp, wp.k + r, pixel, sample, px, py);
+                    }
                     want = false;
                 }
                 wp.k += n_need < avail ? n_need : avail;
                 need &= ~__ballot(mine);
             }
             if (start) {
-                ps = path_start(cam, rp.seed, pixel, px, py, (unsigned)rp.sample_begin + sample);
+                if constexpr (RING) { // (the host does not pick this variant for max_depth <= 0)
+                    ps.beta = mk(1.0f, 1.0f, 1.0f);
+                    ps.L = mk(0.0f, 0.0f, 0.0f);
+                    ps.depth = cam.max_depth;
+                } else {
+                    ps = path_start(cam, rp.seed, pixel, px, py, (unsigned)rp.sample_begin + sample);
+                }
                 if (ps.depth > 0) {
                     n_rays = 1;
-                    trav_begin(tv, ps.ray, RT_INF);
+                    begin = true;
                     state = ST_TRAV;
                 } else { // max_depth 0: camera.h:141
                     write_record(rp, sample, pixel, mk(0.0f, 0.0f, 0.0f), 0u);
                 }
             }
         }
+        // scattered rays and camera rays set their traversal up together (more lanes per instruction)
+        if (begin) trav_begin(tv, ps.ray, RT_INF);
         RT_TOCK(c_regen);
         const bool pool_dry = TAIL || (wp.exhausted && wp.k >= wp.k_end);
         if constexpr (!TAIL) {
@@ -548,14 +584,14 @@ static hipError_t launch_mega_tc(const DevScene &sc, const DevCamera &cam, const
     return hipGetLastError();
 }
 
-template <bool LDS_SCENE>
+template <bool LDS_SCENE, bool RING>
 static hipError_t launch_mega_bvh_tc(const DevScene &sc, const DevCamera &cam, const RenderParams &rp,
                                      const LaunchGeom &lg, hipStream_t stream) {
     if (rp.counters)
-        hipLaunchKernelGGL((render_mega_bvh<LDS_SCENE, true>), dim3(lg.grid), dim3(lg.block), lg.lds_bytes,
+        hipLaunchKernelGGL((render_mega_bvh<LDS_SCENE, true, RING>), dim3(lg.grid), dim3(lg.block), lg.lds_bytes,
                            stream, sc, cam, rp);
     else
-        hipLaunchKernelGGL((render_mega_bvh<LDS_SCENE, false>), dim3(lg.grid), dim3(lg.block), lg.lds_bytes,
+        hipLaunchKernelGGL((render_mega_bvh<LDS_SCENE, false, RING>), dim3(lg.grid), dim3(lg.block), lg.lds_bytes,
                            stream, sc, cam, rp);
     return hipGetLastError();
 }
@@ -568,8 +604,12 @@ hipError_t RT_LAUNCH_NAME(launch_mega)(const DevScene &sc, const DevCamera &cam,
     if (rp.scheduler == 0)
         return lg.lds_scene ? launch_mega_tc<TRAV_BVH, true>(sc, cam, rp, lg, stream)
                             : launch_mega_tc<TRAV_BVH, false>(sc, cam, rp, lg, stream);
-    return lg.lds_scene ? launch_mega_bvh_tc<true>(sc, cam, rp, lg, stream)
-                        : launch_mega_bvh_tc<false>(sc, cam, rp, lg, stream);
+    // the ring variant starts every path with depth > 0 (camera.h:141 is the other one's business)
+    if (lg.ring && cam.max_depth > 0)
+        return lg.lds_scene ? launch_mega_bvh_tc<true, true>(sc, cam, rp, lg, stream)
+                            : launch_mega_bvh_tc<false, true>(sc, cam, rp, lg, stream);
+    return lg.lds_scene ? launch_mega_bvh_tc<true, false>(sc, cam, rp, lg, stream)
+                        : launch_mega_bvh_tc<false, false>(sc, cam, rp, lg, stream);
 }
 
 #ifndef RT_LEAN
@@ -578,8 +618,8 @@ int mega_waves_per_simd() { return RT_MEGA_WAVES_PER_SIMD; }
 // Workgroups of the decoupled render kernel the runtime will keep resident per CU.
 int mega_blocks_per_cu(int block, int lds_bytes, bool lds_scene) {
     int n = 0;
-    hipError_t e = lds_scene ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_mega_bvh<true, false>, block, lds_bytes)
-                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_mega_bvh<false, false>, block, lds_bytes);
+    hipError_t e = lds_scene ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_mega_bvh<true, false, false>, block, lds_bytes)
+                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_mega_bvh<false, false, false>, block, lds_bytes);
     return e == hipSuccess ? n : -1;
 }
 #endif // !RT_LEAN
@@ -601,7 +641,10 @@ hipError_t RT_LAUNCH_NAME(set_mega_lds_limit)(int bytes) {
 #undef RT_SET
 #define RT_SET2(L, C)                                                                                        \
     if (e == hipSuccess)                                                                                     \
-        e = hipFuncSetAttribute((const void *)render_mega_bvh<L, C>,                                         \
+        e = hipFuncSetAttribute((const void *)render_mega_bvh<L, C, false>,                                  \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes);                          \
+    if (e == hipSuccess)                                                                                     \
+        e = hipFuncSetAttribute((const void *)render_mega_bvh<L, C, true>,                                   \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     RT_SET2(true, true)
     RT_SET2(true, false)

@@ -30,6 +30,7 @@ struct RenderParams {
     unsigned n_strips;             // ceil(n_pixels / 64)
     unsigned n_units;              // n_strips * sample_count: units of 64 paths (rt_wavepool.h)
     int pixel_major;               // order of the units: 0 sample-major, 1 pixel-major
+    int ring_f4;                   // camera-ray rings (LaunchGeom::ring): their offset in dynamic LDS, 16-byte words
     rtc::f4 *stage;                // [sample_count][n_pixels] {r g b rays}
     unsigned *next_chunk;          // pool counter, zeroed before the launch
     rtc::Counters *counters;       // non-null: count tests (instrumented kernel variant)
@@ -61,7 +62,12 @@ struct LaunchGeom {
     bool lds_scene;  // slots + nodes are staged into LDS
     int lds_records; // ... and so are the per-slot records and the texture table
     int pool_slots;  // render_pool_bvh: path slots per wave (0: this geometry is not for it)
+    // decoupled kernel: every wave keeps the 64 camera rays of its current unit in LDS (generated
+    // by all lanes at once when the unit is taken; idle lanes then only fetch theirs)
+    bool ring = false;
+    int ring_f4 = 0; // offset of the rings in dynamic LDS, in 16-byte words
 };
+#define RT_RING_F4_PER_WAVE (3 * 64) // {origin, time} {direction, sampler state} {pixel, local sample, -, -}
 
 // Path state of the wavefront variant: structure-of-arrays over the in-flight path slots.
 struct WfBuffers {

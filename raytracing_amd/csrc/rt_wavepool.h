@@ -77,8 +77,9 @@ __device__ __forceinline__ void pool_init(WavePool &wp) {
 // Makes sure the wave holds a unit with paths left, if the launch has any; it may come back
 // empty-handed without the launch being over (another wave is fetching the workgroup's next
 // run): the caller tries again on its next turn.  Wave-uniform.
-__device__ __forceinline__ void pool_refill(WavePool &wp, BlockPool *bp, const RenderParams &rp, int lane) {
-    if (wp.k < wp.k_end || wp.exhausted) return;
+// Returns true when the wave has just taken a new unit.
+__device__ __forceinline__ bool pool_refill(WavePool &wp, BlockPool *bp, const RenderParams &rp, int lane) {
+    if (wp.k < wp.k_end || wp.exhausted) return false;
     const unsigned NOTHING = ~0u, DRY = ~0u - 1u;
     unsigned unit = NOTHING;
     if (lane == 0) {
@@ -125,10 +126,10 @@ __device__ __forceinline__ void pool_refill(WavePool &wp, BlockPool *bp, const R
         }
     }
     unit = wave_bcast32(unit);
-    if (unit == NOTHING) return;
+    if (unit == NOTHING) return false;
     if (unit == DRY) {
         wp.exhausted = true;
-        return;
+        return false;
     }
     unsigned s0, strip0;
     if (rp.pixel_major) { // all samples of a strip in a row: the rays of a workgroup stay together
@@ -144,6 +145,7 @@ __device__ __forceinline__ void pool_refill(WavePool &wp, BlockPool *bp, const R
     wp.first = strip0 * 64u;
     wp.y0 = wp.first / (unsigned)rp.width;
     wp.x0 = wp.first - wp.y0 * (unsigned)rp.width;
+    return true;
 }
 
 #undef RT_LDS_LOAD
