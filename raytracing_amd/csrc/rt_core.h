@@ -241,10 +241,10 @@ RT_HD void sample_unit_disk(Rng &rng, float &px, float &py) {
 // once, for the winner (surface_at).
 
 // sphere::hit up to the accepted root (sphere.h:40-63).  The interval is open.
-RT_HD bool sphere_test(f4 g0, f4 g1, f3 o, f3 d, float tm, float tmin, float tmax, float &t_out) {
+// a = |d|^2 (sphere.h:44), which callers that test many spheres against one ray keep.
+RT_HD bool sphere_test(f4 g0, f4 g1, f3 o, f3 d, float a, float tm, float tmin, float tmax, float &t_out) {
     f3 center = xyz(g0) + tm * xyz(g1); // sphere.h:93 (static spheres carry a zero center_vec)
     f3 oc = center - o;
-    float a = len2(d);
     float h = dot(d, oc);
     float c = len2(oc) - g0.w * g0.w;
     float discriminant = h * h - a * c;
@@ -381,7 +381,7 @@ RT_HD TraceHit trace_linear(const DevScene &sc, const SceneView &v, const Ray &r
         bool h;
         if (!RT_FEAT_QUAD || RT_KIND_PRIM(m.x) == RT_PRIM_SPHERE) {
             RT_COUNT(sph);
-            h = sphere_test(g[0], g[1], o, d, r.tm, tmin, best.t, t);
+            h = sphere_test(g[0], g[1], o, d, len2(d), r.tm, tmin, best.t, t);
             if constexpr (COUNT) cn.sphh += h ? 1 : 0;
         } else {
             RT_COUNT(quad);
@@ -476,9 +476,11 @@ struct Trav {
     int ref;
     int sp; // stack offset in elements (already multiplied by the stride)
     bool best_is_quad;
+    float dd; // |d|^2 of the world-space ray
 };
 RT_HD void trav_begin(Trav &tv, const Ray &r, float tmax) {
     tv.br = make_box_ray(r);
+    tv.dd = len2(r.d);
     tv.best_t = tmax;
     tv.best_slot = -1;
     tv.best_is_quad = false;
@@ -539,14 +541,18 @@ RT_HD void trav_test_leaf(Trav &tv, int leaf_ref, const DevScene &sc, const Scen
     // a primitive inside instance wrappers is tested in its object space (t is the same
     // parameter there: the direction is transformed, not normalised)
     f3 o = r.o, d = r.d;
+    float dd = tv.dd;
     if (RT_FEAT_CHAIN && sc.n_chains > 0) {
         int chain = v.rec_i[s].z;
-        if (chain >= 0) chain_ray_to_object(sc, chain, o, d);
+        if (chain >= 0) {
+            chain_ray_to_object(sc, chain, o, d);
+            dd = len2(d);
+        }
     }
     // candidates at t == best_t are admitted here and sorted out by the tie rule
     if (!is_quad) {
         RT_COUNT(sph);
-        h = sphere_test(g[0], g[1], o, d, r.tm, tmin, RT_INF, t);
+        h = sphere_test(g[0], g[1], o, d, dd, r.tm, tmin, RT_INF, t);
         if constexpr (COUNT) cn.sphh += h ? 1 : 0;
         h = h && t <= tv.best_t;
     } else {
@@ -620,7 +626,7 @@ RT_HD Surf surface_at(const DevScene &sc, const SceneView &vw, const Ray &r, Tra
     if (!RT_FEAT_QUAD || RT_KIND_PRIM(m.x) == RT_PRIM_SPHERE) {
         f4 g0 = g[0], g1 = g[1];
         f3 center = xyz(g0) + r.tm * xyz(g1);
-        outward = (p - center) / g0.w; // sphere.h:68
+        outward = g1.w * (p - center); // sphere.h:68 (g1.w = 1 / radius)
     } else {
         f4 g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
         outward = xyz(g0);

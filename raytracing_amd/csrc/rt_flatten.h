@@ -413,7 +413,8 @@ inline int flatten_scene(const rt_scene_desc *d, uint32_t flags, HostScene &out,
             f3 cv = (p.flags & RT_PRIM_FLAG_MOVING) ? mk(p.b[0], p.b[1], p.b[2]) : mk(0.0f, 0.0f, 0.0f);
             float radius = p.c[0];
             g[0] = f4{c1.x, c1.y, c1.z, radius};
-            g[1] = f4{cv.x, cv.y, cv.z, 0.0f};
+            // .w: the reciprocal sphere.h:68 multiplies by ((p - center) / radius = (1 / radius) * v, vec3.h:107)
+            g[1] = f4{cv.x, cv.y, cv.z, 1.0f / radius};
             if (!linear) {
                 Box3 ob; // object space
                 ob.reset();
