@@ -284,4 +284,32 @@ hipError_t build_lbvh(const float *boxes, const int *types, int n, float **d_nod
 #undef RT_TRY
 }
 
+// Order of a launch's 64-pixel strips for the next launch of the same image: most expensive
+// first (keys from reduce_stage: the sum over the strip's paths of their squared ray counts), so that a
+// launch ends on short paths and its waves run dry and drain together.
+size_t order_strips_tmp_bytes(unsigned n) {
+    size_t bytes = 0;
+    unsigned *k = nullptr;
+    if (rocprim::radix_sort_pairs_desc(nullptr, bytes, k, k, k, k, (size_t)n, 0, 32, (hipStream_t)0) != hipSuccess) return 0;
+    return bytes;
+}
+
+namespace {
+__global__ void iota_kernel(unsigned *v, unsigned n) {
+    unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = i;
+}
+} // namespace
+
+hipError_t fill_iota(unsigned *v, unsigned n, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(iota_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, v, n);
+    return hipGetLastError();
+}
+
+hipError_t order_strips(const unsigned *cost, const unsigned *iota, unsigned n, unsigned *cost_sorted, unsigned *order,
+                        void *tmp, size_t tmp_bytes, hipStream_t stream) {
+    return rocprim::radix_sort_pairs_desc(tmp, tmp_bytes, cost, cost_sorted, iota, order, (size_t)n, 0, 32, stream);
+}
+
 } // namespace rtl

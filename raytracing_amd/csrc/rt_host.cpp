@@ -74,6 +74,14 @@ struct rt_scene {
     unsigned *spill_count[2] = {nullptr, nullptr};
     int spill_waves = 0, spill_max = 0;
     unsigned epoch = 0;
+    // cost-ordered strips (per record set): reduce_stage leaves a cost per 64-pixel strip, sorted
+    // into the order in which the set's next launch of the same image hands the strips out
+    unsigned *strip_cost[2] = {nullptr, nullptr}, *strip_order[2] = {nullptr, nullptr};
+    unsigned strip_valid[2] = {0, 0}; // strips the order covers (0: none yet)
+    unsigned *strip_iota = nullptr, *strip_sorted = nullptr;
+    void *strip_tmp = nullptr;
+    size_t strip_tmp_bytes = 0;
+    unsigned strip_cap = 0;
     unsigned long long *d_words = nullptr; // [0] pool counter, [1] ray counter
     rtc::Counters *d_counters = nullptr;
     int n_cu = 256;
@@ -318,6 +326,8 @@ int rt_scene_destroy(rt_scene *s) {
     hipDeviceSynchronize();
     for (int b = 0; b < 2; b++) {
         if (s->stage[b]) hipFree(s->stage[b]);
+        if (s->strip_cost[b]) hipFree(s->strip_cost[b]);
+        if (s->strip_order[b]) hipFree(s->strip_order[b]);
         if (s->spill[b]) hipFree(s->spill[b]);
         if (s->spill_count[b]) hipFree(s->spill_count[b]);
         if (s->mega_stream[b]) hipStreamDestroy(s->mega_stream[b]);
@@ -340,6 +350,9 @@ int rt_scene_destroy(rt_scene *s) {
         }
         hipFree(s->d_timeline);
     }
+    if (s->strip_iota) hipFree(s->strip_iota);
+    if (s->strip_sorted) hipFree(s->strip_sorted);
+    if (s->strip_tmp) hipFree(s->strip_tmp);
     if (s->wf_mem) hipFree(s->wf_mem);
     if (s->wf_host_cnt) hipHostFree(s->wf_host_cnt);
     for (hipEvent_t e : s->prof_events) hipEventDestroy(e);
@@ -674,6 +687,36 @@ int rt_render_device(rt_scene *s, const rt_camera_desc *cam, const rt_render_opt
         rp.n_strips = (unsigned)((n_pixels + 63) / 64);
         rp.n_units = rp.n_strips * (unsigned)sc_n;
         rp.pixel_major = env_int("RT_AMD_UNIT_ORDER", 1);
+        // Strips in the order of their cost in this set's previous launch (megakernel, scenes in
+        // LDS: for scenes read from HBM neighbouring rays matter more than the tail of the launch)
+        const bool strip_costs = !wavefront && rp.pixel_major && env_int("RT_AMD_STRIP_ORDER", lg.lds_scene ? 1 : 0) != 0;
+        rp.strip_order = nullptr;
+        if (strip_costs) {
+            if (rp.n_strips > s->strip_cap) {
+                RT_HIP(hipDeviceSynchronize());
+                for (int k = 0; k < 2; k++) {
+                    if (s->strip_cost[k]) RT_HIP(hipFree(s->strip_cost[k]));
+                    if (s->strip_order[k]) RT_HIP(hipFree(s->strip_order[k]));
+                    s->strip_cost[k] = s->strip_order[k] = nullptr;
+                    RT_HIP(hipMalloc((void **)&s->strip_cost[k], rp.n_strips * sizeof(unsigned)));
+                    RT_HIP(hipMalloc((void **)&s->strip_order[k], rp.n_strips * sizeof(unsigned)));
+                    s->strip_valid[k] = 0;
+                }
+                if (s->strip_iota) RT_HIP(hipFree(s->strip_iota));
+                if (s->strip_sorted) RT_HIP(hipFree(s->strip_sorted));
+                if (s->strip_tmp) RT_HIP(hipFree(s->strip_tmp));
+                s->strip_iota = s->strip_sorted = nullptr;
+                s->strip_tmp = nullptr;
+                RT_HIP(hipMalloc((void **)&s->strip_iota, rp.n_strips * sizeof(unsigned)));
+                RT_HIP(hipMalloc((void **)&s->strip_sorted, rp.n_strips * sizeof(unsigned)));
+                s->strip_tmp_bytes = std::max<size_t>(rtl::order_strips_tmp_bytes(rp.n_strips), 16);
+                RT_HIP(hipMalloc(&s->strip_tmp, s->strip_tmp_bytes));
+                RT_HIP(rtl::fill_iota(s->strip_iota, rp.n_strips, nullptr));
+                RT_HIP(hipDeviceSynchronize());
+                s->strip_cap = rp.n_strips;
+            }
+            if (s->strip_valid[b] == rp.n_strips) rp.strip_order = s->strip_order[b];
+        }
         rp.ring_f4 = lg.ring_f4;
         rp.stage = s->stage[b];
         rp.next_chunk = reinterpret_cast<unsigned *>(s->d_words + 2 * b); // words 0 / 2: pool counters, 1: rays
@@ -750,7 +793,13 @@ int rt_render_device(rt_scene *s, const rt_camera_desc *cam, const rt_render_opt
             RT_HIP(hipEventRecord(s->ev_done[b], ms));
             RT_HIP(hipStreamWaitEvent(stream, s->ev_done[b], 0));
         }
-        RT_HIP(rtl::launch_reduce(s->stage[b], n_pixels, sc_n, d_accum, s->d_words + 1, stream));
+        RT_HIP(rtl::launch_reduce(s->stage[b], n_pixels, sc_n, d_accum, s->d_words + 1,
+                                  strip_costs ? s->strip_cost[b] : nullptr, stream));
+        if (strip_costs) { // the set's next launch waits for ev_free (pipelined) or follows on this stream
+            RT_HIP(rtl::order_strips(s->strip_cost[b], s->strip_iota, rp.n_strips, s->strip_sorted, s->strip_order[b],
+                                     s->strip_tmp, s->strip_tmp_bytes, stream));
+            s->strip_valid[b] = rp.n_strips;
+        }
         if (pipelined) {
             RT_HIP(hipEventRecord(s->ev_free[b], stream));
             s->ev_free_valid[b] = true;

@@ -482,10 +482,12 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
 // accum[pixel] += sum over the launch's samples, in sample order; ray counts are
 // summed per workgroup and added to *ray_count.
 __global__ void __launch_bounds__(256) reduce_stage(const f4 *stage, int n_pixels, int sample_count,
-                                                    float *accum, unsigned long long *ray_count) {
+                                                    float *accum, unsigned long long *ray_count,
+                                                    unsigned *strip_cost) {
     __shared__ unsigned long long wave_rays[4];
     int pixel = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long rays = 0;
+    unsigned long long squares = 0; // sum of (rays of a path)^2: long paths weigh more than many short ones
     if (pixel < n_pixels) {
         float r = 0.0f, g = 0.0f, b = 0.0f;
         for (int s = 0; s < sample_count; s++) {
@@ -493,14 +495,23 @@ __global__ void __launch_bounds__(256) reduce_stage(const f4 *stage, int n_pixel
             r += v.x;
             g += v.y;
             b += v.z;
-            rays += __builtin_bit_cast(unsigned, v.w);
+            const unsigned n = __builtin_bit_cast(unsigned, v.w);
+            rays += n;
+            squares += (unsigned long long)n * n;
         }
         accum[3 * (size_t)pixel + 0] += r;
         accum[3 * (size_t)pixel + 1] += g;
         accum[3 * (size_t)pixel + 2] += b;
     }
-    for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off, 64);
-    if ((threadIdx.x & 63) == 0) wave_rays[threadIdx.x >> 6] = rays;
+    for (int off = 32; off > 0; off >>= 1) {
+        rays += __shfl_down(rays, off, 64);
+        squares += __shfl_down(squares, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        wave_rays[threadIdx.x >> 6] = rays;
+        // a wave covers one 64-pixel strip: its cost for the next launch's order
+        if (strip_cost && pixel < n_pixels) strip_cost[pixel >> 6] = squares < 0xffffffffull ? (unsigned)squares : 0xffffffffu;
+    }
     __syncthreads();
     if (threadIdx.x == 0)
         atomicAdd(ray_count, wave_rays[0] + wave_rays[1] + wave_rays[2] + wave_rays[3]);
@@ -656,10 +667,10 @@ hipError_t RT_LAUNCH_NAME(set_mega_lds_limit)(int bytes) {
 
 #ifndef RT_LEAN
 hipError_t launch_reduce(const f4 *stage, int n_pixels, int sample_count, float *accum,
-                         unsigned long long *ray_count, hipStream_t stream) {
+                         unsigned long long *ray_count, unsigned *strip_cost, hipStream_t stream) {
     int grid = (n_pixels + 255) / 256;
     hipLaunchKernelGGL(reduce_stage, dim3(grid), dim3(256), 0, stream, stage, n_pixels, sample_count, accum,
-                       ray_count);
+                       ray_count, strip_cost);
     return hipGetLastError();
 }
 

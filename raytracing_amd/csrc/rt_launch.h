@@ -30,6 +30,7 @@ struct RenderParams {
     unsigned n_strips;             // ceil(n_pixels / 64)
     unsigned n_units;              // n_strips * sample_count: units of 64 paths (rt_wavepool.h)
     int pixel_major;               // order of the units: 0 sample-major, 1 pixel-major
+    const unsigned *strip_order;   // pixel-major: the strips in the order they are handed out (null: as they lie)
     int ring_f4;                   // camera-ray rings (LaunchGeom::ring): their offset in dynamic LDS, 16-byte words
     rtc::f4 *stage;                // [sample_count][n_pixels] {r g b rays}
     unsigned *next_chunk;          // pool counter, zeroed before the launch
@@ -100,7 +101,11 @@ hipError_t set_pool_lds_limit(int bytes);
 int mega_waves_per_simd(); // register budget the render kernels were compiled for
 int mega_blocks_per_cu(int block, int lds_bytes, bool lds_scene);
 hipError_t launch_reduce(const rtc::f4 *stage, int n_pixels, int sample_count, float *accum,
-                         unsigned long long *ray_count, hipStream_t stream);
+                         unsigned long long *ray_count, unsigned *strip_cost, hipStream_t stream);
+size_t order_strips_tmp_bytes(unsigned n);
+hipError_t fill_iota(unsigned *v, unsigned n, hipStream_t stream);
+hipError_t order_strips(const unsigned *cost, const unsigned *iota, unsigned n, unsigned *cost_sorted, unsigned *order,
+                        void *tmp, size_t tmp_bytes, hipStream_t stream);
 hipError_t build_lbvh(const float *boxes, const int *types, int n, float **d_nodes_out, int *leaf_order,
                       int *inner_levels);
 hipError_t launch_tonemap(const float *accum, long long n_components, float scale, uint8_t *rgb8,

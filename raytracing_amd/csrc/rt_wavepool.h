@@ -135,6 +135,7 @@ __device__ __forceinline__ bool pool_refill(WavePool &wp, BlockPool *bp, const R
     if (rp.pixel_major) { // all samples of a strip in a row: the rays of a workgroup stay together
         strip0 = unit / (unsigned)rp.sample_count;
         s0 = unit - strip0 * (unsigned)rp.sample_count;
+        if (rp.strip_order) strip0 = rp.strip_order[strip0]; // (a permutation: costly strips first)
     } else {
         s0 = unit / rp.n_strips;
         strip0 = unit - s0 * rp.n_strips;

@@ -262,3 +262,31 @@ def test_pipelined_launches_equal_serial_ones(monkeypatch):
         sc.close()
     assert np.array_equal(results[0], results[1])
     assert results[0].mean() > 0
+
+
+def test_cost_ordered_strips_change_nothing(monkeypatch):
+    """From its second launch of an image on, a scene hands the 64-pixel strips out in the order of
+    their cost in the previous launch (most expensive first).  Same image bit for bit as with the
+    strips in place, for repeated launches, a change of image size in between, and odd sizes."""
+    import torch
+    B = _binding()
+    arrays, cam, _ = load_scene("bouncing_spheres")
+    results = []
+    for order in ("1", "0"):
+        monkeypatch.setenv("RT_AMD_STRIP_ORDER", order)
+        sc = B.Scene(arrays)
+        stream = torch.cuda.current_stream().cuda_stream
+        images = []
+        for width in (160, 160, 131, 160):
+            cam.image_width = width
+            H, W = cam.image_height(), cam.image_width
+            acc = torch.zeros(H, W, 3, device="cuda")
+            for k in range(3):
+                sc.render_device(cam, 6, acc.data_ptr(), stream=stream, sample_begin=6 * k, seed=9)
+            torch.cuda.synchronize()
+            images.append(acc.cpu().numpy())
+        results.append(images)
+        sc.close()
+    for a, b in zip(*results):
+        assert np.array_equal(a, b)
+    assert np.array_equal(results[0][0], results[0][1]) and np.array_equal(results[0][0], results[0][3])
