@@ -198,8 +198,8 @@ LaunchGeom choose_geom(rt_scene *s, uint32_t flags) {
     lg.lds_records = 0;
     lg.pool_slots = 0;
     int bpc = bpc_target;
-    // the decoupled kernel's camera-ray rings (one per wave) come after the stacks if there is room
-    const size_t ring_bytes = bvh && env_int("RT_AMD_RING", 1) != 0
+    // the render kernels' camera-ray rings (one per wave) come after the stacks if there is room
+    const size_t ring_bytes = env_int("RT_AMD_RING", 1) != 0
                                   ? (size_t)(block / 64) * RT_RING_F4_PER_WAVE * sizeof(f4) : 0;
     lg.ring = false;
     lg.ring_f4 = 0;

@@ -41,7 +41,7 @@ namespace {
 // ------------------------------------------------------------------------------------------
 // One whole ray per lane per iteration.  Linear scenes: every lane walks the same
 // primitive list, so the traversal itself is divergence-free.
-template <int TRAV, bool LDS_SCENE, bool COUNT>
+template <int TRAV, bool LDS_SCENE, bool COUNT, bool RING>
 __global__ void __launch_bounds__(RT_MEGA_MAX_THREADS, RT_MEGA_WAVES_PER_SIMD)
 render_mega(DevScene sc, DevCamera cam, RenderParams rp) {
     extern __shared__ f4 smem[];
@@ -54,6 +54,8 @@ render_mega(DevScene sc, DevCamera cam, RenderParams rp) {
     using StackT = typename std::conditional<LDS_SCENE, short, int>::type;
     StackT *stack = reinterpret_cast<StackT *>(free_lds) + threadIdx.x;
     const int stack_stride = blockDim.x;
+    // RING: the camera rays of the wave's current unit (see render_mega_bvh)
+    f4 *ring = RING ? smem + rp.ring_f4 + (size_t)(threadIdx.x >> 6) * RT_RING_F4_PER_WAVE : nullptr;
 
     const int lane = threadIdx.x & 63;
     const unsigned long long lane_mask_lt = (1ull << lane) - 1ull;
@@ -70,19 +72,50 @@ render_mega(DevScene sc, DevCamera cam, RenderParams rp) {
     for (;;) {
         unsigned long long need = __ballot(!alive);
         if (need != 0ull) {
-            pool_refill(wp, &block_pool, rp, lane);
+            const bool new_unit = pool_refill(wp, &block_pool, rp, lane);
             if (wp.k < wp.k_end) {
+                if constexpr (RING) {
+                    if (new_unit) { // all 64 camera rays of the unit at once, with every lane
+                        unsigned g_pixel, g_sample;
+                        int gx, gy;
+                        const bool valid = pool_decode(wp, rp, (unsigned)lane, g_pixel, g_sample, gx, gy);
+                        const PathState g = path_start(cam, rp.seed, g_pixel, gx, gy, (unsigned)rp.sample_begin + g_sample);
+                        ring[lane] = f4{g.ray.o.x, g.ray.o.y, g.ray.o.z, g.ray.tm};
+                        ring[64 + lane] = f4{g.ray.d.x, g.ray.d.y, g.ray.d.z, __builtin_bit_cast(float, g.rng.s)};
+                        ring[128 + lane] = f4{__builtin_bit_cast(float, valid ? g_pixel : ~0u),
+                                              __builtin_bit_cast(float, g_sample), 0.0f, 0.0f};
+                    }
+                }
                 unsigned n_need = (unsigned)__popcll(need);
                 if (!alive) {
                     unsigned k = wp.k + (unsigned)__popcll(need & lane_mask_lt);
-                    int px, py;
-                    unsigned pix, s_local;
-                    if (k < wp.k_end && pool_decode(wp, rp, k, pix, s_local, px, py)) {
-                        pixel = pix;
-                        sample = s_local;
-                        ps = path_start(cam, rp.seed, pixel, px, py, (unsigned)rp.sample_begin + s_local);
-                        n_rays = 0;
-                        alive = true;
+                    if constexpr (RING) {
+                        if (k < wp.k_end) {
+                            const f4 a0 = ring[k], a1 = ring[64 + k], a2 = ring[128 + k];
+                            pixel = __builtin_bit_cast(unsigned, a2.x);
+                            sample = __builtin_bit_cast(unsigned, a2.y);
+                            if (pixel != ~0u) {
+                                ps.ray.o = mk(a0.x, a0.y, a0.z);
+                                ps.ray.tm = a0.w;
+                                ps.ray.d = mk(a1.x, a1.y, a1.z);
+                                ps.rng.s = __builtin_bit_cast(unsigned, a1.w);
+                                ps.beta = mk(1.0f, 1.0f, 1.0f);
+                                ps.L = mk(0.0f, 0.0f, 0.0f);
+                                ps.depth = cam.max_depth;
+                                n_rays = 0;
+                                alive = true;
+                            }
+                        }
+                    } else {
+                        int px, py;
+                        unsigned pix, s_local;
+                        if (k < wp.k_end && pool_decode(wp, rp, k, pix, s_local, px, py)) {
+                            pixel = pix;
+                            sample = s_local;
+                            ps = path_start(cam, rp.seed, pixel, px, py, (unsigned)rp.sample_begin + s_local);
+                            n_rays = 0;
+                            alive = true;
+                        }
                     }
                 }
                 wp.k = wp.k + n_need < wp.k_end ? wp.k + n_need : wp.k_end;
@@ -583,16 +616,22 @@ trace_batch(DevScene sc, const rt_ray *rays, long long n_rays, float tmin, float
 // Host-side launchers (called from rt_host.cpp)
 namespace rtl {
 
+template <int TRAV, bool LDS_SCENE, bool RING>
+static hipError_t launch_mega_tcr(const DevScene &sc, const DevCamera &cam, const RenderParams &rp,
+                                  const LaunchGeom &lg, hipStream_t stream) {
+    if (rp.counters)
+        hipLaunchKernelGGL((render_mega<TRAV, LDS_SCENE, true, RING>), dim3(lg.grid), dim3(lg.block), lg.lds_bytes,
+                           stream, sc, cam, rp);
+    else
+        hipLaunchKernelGGL((render_mega<TRAV, LDS_SCENE, false, RING>), dim3(lg.grid), dim3(lg.block), lg.lds_bytes,
+                           stream, sc, cam, rp);
+    return hipGetLastError();
+}
 template <int TRAV, bool LDS_SCENE>
 static hipError_t launch_mega_tc(const DevScene &sc, const DevCamera &cam, const RenderParams &rp,
                                  const LaunchGeom &lg, hipStream_t stream) {
-    if (rp.counters)
-        hipLaunchKernelGGL((render_mega<TRAV, LDS_SCENE, true>), dim3(lg.grid), dim3(lg.block), lg.lds_bytes,
-                           stream, sc, cam, rp);
-    else
-        hipLaunchKernelGGL((render_mega<TRAV, LDS_SCENE, false>), dim3(lg.grid), dim3(lg.block), lg.lds_bytes,
-                           stream, sc, cam, rp);
-    return hipGetLastError();
+    return lg.ring ? launch_mega_tcr<TRAV, LDS_SCENE, true>(sc, cam, rp, lg, stream)
+                   : launch_mega_tcr<TRAV, LDS_SCENE, false>(sc, cam, rp, lg, stream);
 }
 
 template <bool LDS_SCENE, bool RING>
@@ -639,7 +678,10 @@ hipError_t RT_LAUNCH_NAME(set_mega_lds_limit)(int bytes) {
     hipError_t e = hipSuccess;
 #define RT_SET(TR, L, C)                                                                                     \
     if (e == hipSuccess)                                                                                     \
-        e = hipFuncSetAttribute((const void *)render_mega<TR, L, C>,                                         \
+        e = hipFuncSetAttribute((const void *)render_mega<TR, L, C, false>,                                  \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes);                          \
+    if (e == hipSuccess)                                                                                     \
+        e = hipFuncSetAttribute((const void *)render_mega<TR, L, C, true>,                                   \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     RT_SET(TRAV_LINEAR, true, true)
     RT_SET(TRAV_LINEAR, true, false)
