@@ -50,10 +50,10 @@ def algorithmic_flops(st):
     return float(f)
 
 
-def measured_traffic(scene, width, height, spp):
-    """HBM bytes per launch of the render kernel from the PMC passes committed under profiles/
-    (FETCH_SIZE / WRITE_SIZE cannot be read from inside this process); None if no profile
-    matches the workload."""
+def measured_traffic(scene, width, height, spp, key="traffic_bytes_per_launch"):
+    """HBM bytes per launch of the render kernel (or, with key="pmc", its VALU counters) from the
+    PMC passes committed under profiles/ (hardware counters cannot be read from inside this
+    process); None if no profile matches the workload."""
     best = None
     pdir = os.path.join(ROOT, "profiles")
     for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
@@ -64,7 +64,7 @@ def measured_traffic(scene, width, height, spp):
                 t = json.load(f)
             w = t["workload"]
             if (w["scene"], w["width"], w["height"], w["spp_per_launch"]) == (scene, width, height, spp):
-                best = float(t["traffic_bytes_per_launch"])
+                best = t[key] if key == "pmc" else float(t[key])
         except (OSError, KeyError, ValueError):
             continue
     return best
@@ -220,6 +220,7 @@ def main():
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS,
                          "traffic": measured_traffic(args.scene, W, H, args.spp), "traffic_unit": "bytes/launch",
+                         "pmc": measured_traffic(args.scene, W, H, args.spp, key="pmc"),
                          "kernel": "render_mega_bvh" if info.n_nodes else "render_mega", "kernel_ms_avg": avg_kernel_s * 1e3,
                          "kernel_ms_overlapped_avg": kernel_ms / max(n_launches, 1),
                          "launch_interval_ms": elapsed / max(n_launches, 1) * 1e3,
