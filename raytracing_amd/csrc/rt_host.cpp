@@ -391,6 +391,7 @@ int rt_scene_create(const rt_scene_desc *d, int device, uint32_t flags, rt_scene
                 return true;
             };
         if (env_int("RT_AMD_FORCE_BVH", 0)) flags |= RT_SCENE_FORCE_BVH; // experiments: a tree for small scenes too
+        if (env_int("RT_AMD_FORCE_GLOBAL", 0)) flags |= RT_SCENE_FORCE_GLOBAL; // ... no LDS copy of the scene
         rc = rtf::flatten_scene(d, flags, hs, err, device_builder);
         if (rc != RT_OK) {
             if (d_built_nodes) hipFree(d_built_nodes);
