@@ -93,3 +93,27 @@ def test_schedulers_and_kernel_variants_agree(monkeypatch):
     for no_lean, sched, acc, rays in images[1:]:
         assert rays == images[0][3], (no_lean, sched)
         assert np.array_equal(acc, images[0][2]), (no_lean, sched)
+    # ... and with or without the per-wave LDS rings of camera rays, the scene copy in LDS, or
+    # the tree built over an 18-quad scene that would otherwise be scanned
+    monkeypatch.delenv("RT_AMD_NO_LEAN")
+    for knob in ("RT_AMD_RING", "RT_AMD_FORCE_GLOBAL"):
+        monkeypatch.setenv(knob, "0" if knob == "RT_AMD_RING" else "1")   # read by rt_scene_create
+        sc = B.Scene(arrays)
+        for sched in ("0", "1"):
+            monkeypatch.setenv("RT_AMD_SCHEDULER", sched)
+            acc, st = sc.render(cam, 6, seed=9)
+            assert st.rays == images[0][3] and np.array_equal(acc, images[0][2]), (knob, sched)
+        sc.close()
+        monkeypatch.delenv(knob)
+    monkeypatch.delenv("RT_AMD_SCHEDULER")
+    arrays, cam, _ = load_scene("cornell_box")
+    cam.image_width = 96
+    ref = None
+    for ring in ("1", "0"):
+        monkeypatch.setenv("RT_AMD_RING", ring)
+        sc = B.Scene(arrays)
+        acc, st = sc.render(cam, 5, seed=2)
+        sc.close()
+        if ref is None:
+            ref = (acc, st.rays)
+        assert st.rays == ref[1] and np.array_equal(acc, ref[0])
