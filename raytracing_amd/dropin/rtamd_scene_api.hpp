@@ -313,64 +313,112 @@ class Recorder {
 };
 
 // Minimal PNG writer (8-bit RGB, stored deflate blocks): what camera::render needs to put its
-// pixels on disk (camera.h:56).  The file decodes to exactly the bytes passed in.
-inline bool write_png_rgb8(const char *path, int w, int h, const uint8_t *rgb) {
-    auto crc32 = [](const uint8_t *p, size_t n, uint32_t c) {
-        static uint32_t table[256];
-        static bool init = false;
-        if (!init) {
-            for (uint32_t i = 0; i < 256; i++) {
-                uint32_t v = i;
-                for (int k = 0; k < 8; k++) v = (v & 1) ? 0xEDB88320u ^ (v >> 1) : v >> 1;
-                table[i] = v;
-            }
-            init = true;
+// pixels on disk (camera.h:56).  The file decodes to exactly the bytes passed in.  At GPU
+// rendering speeds this is host time that shows: the checksums run at memory speed (CRC-32
+// eight bytes at a time, Adler-32 with the modulo taken once per 5552 bytes) and the file is
+// assembled once.
+struct PngCrc {
+    uint32_t t[8][256];
+    PngCrc() {
+        for (uint32_t i = 0; i < 256; i++) {
+            uint32_t v = i;
+            for (int k = 0; k < 8; k++) v = (v & 1) ? 0xEDB88320u ^ (v >> 1) : v >> 1;
+            t[0][i] = v;
         }
+        for (uint32_t i = 0; i < 256; i++)
+            for (int k = 1; k < 8; k++) t[k][i] = t[0][t[k - 1][i] & 255] ^ (t[k - 1][i] >> 8);
+    }
+    uint32_t run(const uint8_t *p, size_t n, uint32_t c) const { // c: running value, start with 0
         c = ~c;
-        for (size_t i = 0; i < n; i++) c = table[(c ^ p[i]) & 255] ^ (c >> 8);
+        while (n >= 8) {
+            uint32_t lo, hi;
+            memcpy(&lo, p, 4);
+            memcpy(&hi, p + 4, 4);
+            lo ^= c; // (little-endian hosts; the reference's platforms are)
+            c = t[7][lo & 255] ^ t[6][(lo >> 8) & 255] ^ t[5][(lo >> 16) & 255] ^ t[4][lo >> 24] ^
+                t[3][hi & 255] ^ t[2][(hi >> 8) & 255] ^ t[1][(hi >> 16) & 255] ^ t[0][hi >> 24];
+            p += 8;
+            n -= 8;
+        }
+        while (n--) c = t[0][(c ^ *p++) & 255] ^ (c >> 8);
         return ~c;
+    }
+};
+
+inline bool write_png_rgb8(const char *path, int w, int h, const uint8_t *rgb) {
+    static const PngCrc crc;
+    const size_t row = (size_t)3 * w + 1, raw_bytes = row * h;
+    const size_t n_blocks = raw_bytes ? (raw_bytes + 65534) / 65535 : 1;
+    const size_t z_bytes = 2 + 5 * n_blocks + raw_bytes + 4;
+    std::vector<uint8_t> out;
+    out.reserve(8 + 25 + 12 + z_bytes + 12);
+    auto be32 = [&](uint32_t x) {
+        for (int s = 24; s >= 0; s -= 8) out.push_back((uint8_t)(x >> s));
     };
-    auto be32 = [](std::vector<uint8_t> &v, uint32_t x) {
-        for (int s = 24; s >= 0; s -= 8) v.push_back((uint8_t)(x >> s));
-    };
-    std::vector<uint8_t> raw;
-    raw.reserve((size_t)h * (3 * w + 1));
-    for (int y = 0; y < h; y++) {
-        raw.push_back(0); // filter: none
-        raw.insert(raw.end(), rgb + (size_t)y * w * 3, rgb + (size_t)(y + 1) * w * 3);
-    }
-    std::vector<uint8_t> z = {0x78, 0x01};
-    uint32_t a = 1, b = 0;
-    for (uint8_t c : raw) {
-        a = (a + c) % 65521u;
-        b = (b + a) % 65521u;
-    }
-    for (size_t off = 0; off < raw.size() || off == 0; off += 65535) {
-        size_t n = std::min<size_t>(65535, raw.size() - off);
-        z.push_back(off + n >= raw.size() ? 1 : 0);
-        z.push_back((uint8_t)(n & 255));
-        z.push_back((uint8_t)(n >> 8));
-        z.push_back((uint8_t)(~n & 255));
-        z.push_back((uint8_t)((~n >> 8) & 255));
-        z.insert(z.end(), raw.begin() + off, raw.begin() + off + n);
-        if (raw.empty()) break;
-    }
-    be32(z, (b << 16) | a);
-    std::vector<uint8_t> out = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
-    auto chunk = [&](const char *tag, const std::vector<uint8_t> &data) {
-        be32(out, (uint32_t)data.size());
+    auto begin_chunk = [&](const char *tag, size_t bytes) {
+        be32((uint32_t)bytes);
         size_t start = out.size();
         out.insert(out.end(), tag, tag + 4);
-        out.insert(out.end(), data.begin(), data.end());
-        be32(out, crc32(out.data() + start, out.size() - start, 0));
+        return start;
     };
-    std::vector<uint8_t> ihdr;
-    be32(ihdr, (uint32_t)w);
-    be32(ihdr, (uint32_t)h);
-    ihdr.insert(ihdr.end(), {8, 2, 0, 0, 0});
-    chunk("IHDR", ihdr);
-    chunk("IDAT", z);
-    chunk("IEND", {});
+    auto end_chunk = [&](size_t start) { be32(crc.run(out.data() + start, out.size() - start, 0)); };
+    static const uint8_t magic[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    out.insert(out.end(), magic, magic + 8);
+    size_t c0 = begin_chunk("IHDR", 13);
+    be32((uint32_t)w);
+    be32((uint32_t)h);
+    static const uint8_t fmt[5] = {8, 2, 0, 0, 0};
+    out.insert(out.end(), fmt, fmt + 5);
+    end_chunk(c0);
+
+    c0 = begin_chunk("IDAT", z_bytes);
+    out.push_back(0x78);
+    out.push_back(0x01);
+    // the filtered scanlines (filter byte 0 + pixels) flow straight into stored blocks
+    size_t in_block = 0, left = raw_bytes;
+    auto open_block = [&]() {
+        size_t n = std::min<size_t>(65535, left);
+        out.push_back(left <= 65535 ? 1 : 0);
+        out.push_back((uint8_t)(n & 255));
+        out.push_back((uint8_t)(n >> 8));
+        out.push_back((uint8_t)(~n & 255));
+        out.push_back((uint8_t)((~n >> 8) & 255));
+        in_block = n;
+    };
+    auto put = [&](const uint8_t *p, size_t n) {
+        while (n > 0) {
+            if (in_block == 0) open_block();
+            size_t m = std::min(n, in_block);
+            out.insert(out.end(), p, p + m);
+            p += m;
+            n -= m;
+            in_block -= m;
+            left -= m;
+        }
+    };
+    if (raw_bytes == 0) open_block();
+    uint64_t a = 1, b = 0; // Adler-32 of the scanlines, modulo taken once per scanline piece
+    const uint8_t zero = 0;
+    for (int y = 0; y < h; y++) {
+        const uint8_t *px = rgb + (size_t)y * w * 3;
+        put(&zero, 1); // filter: none
+        put(px, (size_t)w * 3);
+        b += a; // the filter byte adds 0 to a
+        for (size_t i = 0, n = (size_t)w * 3; i < n;) {
+            size_t run = std::min<size_t>(n - i, 1u << 16); // a, b stay far below 2^64
+            for (size_t k = 0; k < run; k++) {
+                a += px[i + k];
+                b += a;
+            }
+            a %= 65521u;
+            b %= 65521u;
+            i += run;
+        }
+    }
+    be32((uint32_t)((b << 16) | a));
+    end_chunk(c0);
+    c0 = begin_chunk("IEND", 0);
+    end_chunk(c0);
     FILE *f = fopen(path, "wb");
     if (!f) return false;
     bool ok = fwrite(out.data(), 1, out.size(), f) == out.size();
