@@ -293,3 +293,36 @@ def test_cost_ordered_strips_change_nothing(monkeypatch):
     for a, b in zip(*results):
         assert np.array_equal(a, b)
     assert np.array_equal(results[0][0], results[0][1]) and np.array_equal(results[0][0], results[0][3])
+
+
+def test_eight_way_sample_split_equals_one_render():
+    """The multi-GPU partition at the headline size (400x225, 100 spp per GPU, 8 GPUs): the eight
+    sample ranges of spp_split.sample_range, rendered one after the other into separate images and
+    summed in rank order, equal the 800-spp render up to the order of the fp32 additions; ray
+    counts add up exactly."""
+    import torch
+    from raytracing_amd import spp_split
+    B = _binding()
+    arrays, cam, _ = load_scene("bouncing_spheres")
+    H, W = cam.image_height(), cam.image_width
+    assert (W, H) == (400, 225)
+    sc = B.Scene(arrays)
+    stream = torch.cuda.current_stream().cuda_stream
+    world, total = 8, 800
+    whole = torch.zeros(H, W, 3, device="cuda")
+    st = sc.render_device(cam, total, whole.data_ptr(), stream=stream, sample_begin=0, seed=0, want_stats=True)
+    summed = torch.zeros(H, W, 3, device="cuda", dtype=torch.float64)
+    rays = 0
+    covered = 0
+    for rank in range(world):
+        begin, count = spp_split.sample_range(total, rank, world)
+        assert begin == covered and count == 100
+        covered += count
+        part = torch.zeros(H, W, 3, device="cuda")
+        sr = sc.render_device(cam, count, part.data_ptr(), stream=stream, sample_begin=begin, seed=0, want_stats=True)
+        rays += int(sr.rays)
+        summed += part.double()
+    torch.cuda.synchronize()
+    assert covered == total and rays == int(st.rays)
+    assert torch.allclose(summed.float(), whole, rtol=2e-5, atol=1e-5)
+    sc.close()
