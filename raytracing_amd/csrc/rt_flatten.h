@@ -4,10 +4,13 @@
 #pragma once
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rt_amd.h"
@@ -22,6 +25,7 @@ using rtc::mk;
 
 const int kLinearMaxPrims = 32;       // at most this many primitives: scan, no tree
 const int kMaxLdsBytes = 160 * 1024;  // LDS per CU on gfx950
+const int kParallelBuildMinPrims = 65536; // scenes from this size on: subtrees built by several threads
 const int kTreeTopMin = 2560;         // trees of at least this many 64-byte nodes never fit LDS whole
 const int kTreeTopMax = 2048;         // nodes moved to the front for the LDS copy of the tree's top
 const int kMaxInnerDepth = RT_STACK_DEPTH - 2;
@@ -212,34 +216,113 @@ class BvhBuilder {
         }
     }
 
-    BvhOut run() {
-        out_.nodes.reserve(idx_.size() * 4);
-        out_.leaf_order.reserve(idx_.size());
+    // Large scenes: the top of the tree is split on this thread until the subtrees are small, the
+    // subtrees are built by a few threads (they own disjoint ranges of the index array), and the
+    // pieces are joined; splits, leaf order and therefore the tree are the same as built by one thread.
+    BvhOut run(int n_threads = 0) {
+        const int n = (int)idx_.size();
+        if (n_threads <= 0) {
+            n_threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+            if (const char *e = getenv("RT_AMD_BUILD_THREADS")) n_threads = std::max(1, atoi(e));
+        }
         Box3 b;
-        build(0, (int)idx_.size(), 0, b);
+        if (n < kParallelBuildMinPrims || n_threads < 2) {
+            out_.nodes.reserve((size_t)n * 4);
+            out_.leaf_order.reserve(n);
+            build(0, n, 0, b, out_, 0);
+            return std::move(out_);
+        }
+        tasks_.clear();
+        build(0, n, 0, b, out_, std::max(1024, n / (n_threads * 8)));
+        std::atomic<size_t> next(0);
+        auto work = [&]() {
+            for (size_t t = next++; t < tasks_.size(); t = next++) {
+                Task &k = tasks_[t];
+                Box3 tb;
+                k.out.nodes.reserve((size_t)k.count * 4);
+                k.out.leaf_order.reserve(k.count);
+                k.ref = build(k.first, k.count, k.depth, tb, k.out, 0);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int i = 1; i < n_threads; i++) pool.emplace_back(work);
+        work();
+        for (std::thread &th : pool) th.join();
+        // join: task t's nodes follow the top nodes and the earlier tasks', its slots the earlier tasks'
+        const int n_top = (int)(out_.nodes.size() / 4);
+        std::vector<int> node_base(tasks_.size()), slot_base(tasks_.size());
+        int nodes_total = n_top, slots_total = 0;
+        for (size_t t = 0; t < tasks_.size(); t++) {
+            node_base[t] = nodes_total;
+            slot_base[t] = slots_total;
+            nodes_total += (int)(tasks_[t].out.nodes.size() / 4);
+            slots_total += (int)tasks_[t].out.leaf_order.size();
+        }
+        auto moved = [&](int ref, size_t t) {
+            if (ref >= 0) return ref + node_base[t];
+            int code = ~ref;
+            return ~((((code >> 1) + slot_base[t]) << 1) | (code & 1));
+        };
+        out_.nodes.resize((size_t)nodes_total * 4);
+        out_.leaf_order.resize(slots_total);
+        for (int i = 0; i < n_top; i++) { // placeholders in the top nodes
+            f4 &r = out_.nodes[(size_t)i * 4 + 3];
+            int r0 = __builtin_bit_cast(int, r.x), r1 = __builtin_bit_cast(int, r.y);
+            if (r0 >= kTaskRef) r.x = __builtin_bit_cast(float, moved(tasks_[r0 - kTaskRef].ref, (size_t)(r0 - kTaskRef)));
+            if (r1 >= kTaskRef) r.y = __builtin_bit_cast(float, moved(tasks_[r1 - kTaskRef].ref, (size_t)(r1 - kTaskRef)));
+        }
+        for (size_t t = 0; t < tasks_.size(); t++) {
+            const BvhOut &o = tasks_[t].out;
+            for (size_t i = 0; i < o.nodes.size() / 4; i++) {
+                f4 *q = &out_.nodes[((size_t)node_base[t] + i) * 4];
+                memcpy(q, &o.nodes[i * 4], 4 * sizeof(f4));
+                q[3].x = __builtin_bit_cast(float, moved(__builtin_bit_cast(int, q[3].x), t));
+                q[3].y = __builtin_bit_cast(float, moved(__builtin_bit_cast(int, q[3].y), t));
+            }
+            std::copy(o.leaf_order.begin(), o.leaf_order.end(), out_.leaf_order.begin() + slot_base[t]);
+            out_.max_inner_depth = std::max(out_.max_inner_depth, o.max_inner_depth);
+        }
+        tasks_.clear();
         return std::move(out_);
     }
 
   private:
+    static const int kTaskRef = 1 << 30; // child references >= this name a task of the parallel build
+    struct Task {
+        int first, count, depth;
+        BvhOut out;
+        int ref = 0;
+    };
+    std::vector<Task> tasks_;
+
     static int ceil_log2(int n) {
         int l = 0;
         while ((1 << l) < n) l++;
         return l;
     }
 
-    // Builds the subtree over idx_[first, first+count) and returns its reference.
-    int build(int first, int count, int depth, Box3 &box) {
+    // Builds the subtree over idx_[first, first+count) into `out` and returns its reference.
+    // task_size > 0: subtrees of at most that many primitives are only recorded as tasks.
+    int build(int first, int count, int depth, Box3 &box, BvhOut &out, int task_size) {
         box.reset();
         for (int i = first; i < first + count; i++) box.add(boxes_[idx_[i]]);
+        if (task_size > 0 && count <= task_size) {
+            Task k;
+            k.first = first;
+            k.count = count;
+            k.depth = depth;
+            tasks_.push_back(std::move(k));
+            return kTaskRef + (int)tasks_.size() - 1;
+        }
         if (count == 1) {
             int prim = idx_[first];
-            int slot = (int)out_.leaf_order.size();
-            out_.leaf_order.push_back(prim);
+            int slot = (int)out.leaf_order.size();
+            out.leaf_order.push_back(prim);
             return ~(slot * 2 + (types_[prim] == RT_PRIM_QUAD ? 1 : 0));
         }
-        out_.max_inner_depth = std::max(out_.max_inner_depth, depth);
-        int node = (int)(out_.nodes.size() / 4);
-        out_.nodes.resize(out_.nodes.size() + 4);
+        out.max_inner_depth = std::max(out.max_inner_depth, depth);
+        int node = (int)(out.nodes.size() / 4);
+        out.nodes.resize(out.nodes.size() + 4);
 
         int mid = split_sah(first, count);
         int nl = mid - first, nr = count - nl;
@@ -248,9 +331,9 @@ class BvhBuilder {
         if (!ok) mid = split_median(first, count);
 
         Box3 b0, b1;
-        int r0 = build(first, mid - first, depth + 1, b0);
-        int r1 = build(mid, first + count - mid, depth + 1, b1);
-        f4 *n = &out_.nodes[(size_t)node * 4];
+        int r0 = build(first, mid - first, depth + 1, b0, out, task_size);
+        int r1 = build(mid, first + count - mid, depth + 1, b1, out, task_size);
+        f4 *n = &out.nodes[(size_t)node * 4];
         // boxes are stored as centre + half extent (rounded up so that the stored box contains
         // the built one): the slab test then needs no per-axis min / max
         float c0[3], h0[3], c1[3], h1[3];

@@ -210,6 +210,44 @@ def test_synth_full_size_sample_ranges_add_up(tmp_path):
     sc.close()
 
 
+def test_parallel_host_build_gives_the_same_tree(tmp_path, monkeypatch):
+    """Scenes of 65 536 primitives or more have their subtrees built by several host threads: the
+    tree must be the one a single thread builds (same boxes, same leaves, child for child; only
+    the numbering of the nodes may differ), with the same closest hits."""
+    B = _binding()
+    arrays, cam = _synth(tmp_path, 180)
+    assert len(arrays.prims) == 360 * 360 + 1
+    rng = np.random.default_rng(21)
+    rays = _camera_rays(cam, 4000, rng)
+    trees, hits, times = [], [], []
+    for threads in ("1", "6"):
+        monkeypatch.setenv("RT_AMD_BUILD_THREADS", threads)
+        sc = B.Scene(arrays)
+        info = sc.info()
+        trees.append((sc.nodes(), info.n_nodes, info.bvh_depth))
+        hits.append(sc.trace(rays))
+        times.append(info.build_ms)
+        sc.close()
+    print(f"host build of {len(arrays.prims)} primitives: {times[0]:.0f} ms with 1 thread, {times[1]:.0f} ms with 6")
+    assert trees[0][1:] == trees[1][1:]
+    assert np.array_equal(hits[0]["prim"], hits[1]["prim"]) and np.array_equal(hits[0]["t"], hits[1]["t"])
+    a, b = trees[0][0], trees[1][0]
+    ra, rb = a[:, 12:14].view(np.int32), b[:, 12:14].view(np.int32)
+    todo, seen = [(0, 0)], 0
+    while todo:
+        i, j = todo.pop()
+        seen += 1
+        assert np.array_equal(a[i, :12], b[j, :12]), "child boxes differ"
+        for k in range(2):
+            x, y = int(ra[i, k]), int(rb[j, k])
+            assert (x >= 0) == (y >= 0)
+            if x >= 0:
+                todo.append((x, y))
+            else:
+                assert x == y, "leaf slots differ"
+    assert seen == trees[0][1]
+
+
 def _tree_stats(nodes):
     """Walks a BVH read back with rt_scene_read_nodes: inner levels, inner nodes reached, distinct
     leaf slots, child boxes that stick out of their parent's box."""
