@@ -221,6 +221,8 @@ def main():
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS,
                          "traffic": measured_traffic(args.scene, W, H, args.spp), "traffic_unit": "bytes/launch",
                          "pmc": measured_traffic(args.scene, W, H, args.spp, key="pmc"),
+                         "hbm_gb_per_s": (measured_traffic(args.scene, W, H, args.spp) or 0.0) / avg_kernel_s * 1e-9
+                         if avg_kernel_s > 0 else None,  # against ~8000: the path is not HBM-bound
                          "kernel": "render_mega_bvh" if info.n_nodes else "render_mega", "kernel_ms_avg": avg_kernel_s * 1e3,
                          "kernel_ms_overlapped_avg": kernel_ms / max(n_launches, 1),
                          "launch_interval_ms": elapsed / max(n_launches, 1) * 1e3,
