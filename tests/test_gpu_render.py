@@ -326,3 +326,30 @@ def test_eight_way_sample_split_equals_one_render():
     assert covered == total and rays == int(st.rays)
     assert torch.allclose(summed.float(), whole, rtol=2e-5, atol=1e-5)
     sc.close()
+
+
+def test_two_scenes_on_two_streams_interleaved():
+    """Two scenes rendered in turn, each from its own stream, without any synchronisation in
+    between: every scene owns its record sets, internal streams and strip order, so the images
+    must be the ones each scene gives on its own."""
+    import torch
+    B = _binding()
+    jobs = []
+    for name, width in (("bouncing_spheres", 192), ("quads", 160), ("simple_light", 128)):
+        arrays, cam, _ = load_scene(name)
+        cam.image_width = width
+        sc = B.Scene(arrays)
+        H, W = cam.image_height(), cam.image_width
+        alone = torch.zeros(H, W, 3, device="cuda")
+        for k in range(4):
+            sc.render_device(cam, 5, alone.data_ptr(), stream=torch.cuda.current_stream().cuda_stream,
+                             sample_begin=5 * k, seed=13)
+        torch.cuda.synchronize()
+        jobs.append((sc, cam, torch.cuda.Stream(), torch.zeros(H, W, 3, device="cuda"), alone))
+    for k in range(4):
+        for sc, cam, stream, acc, _ in jobs:
+            sc.render_device(cam, 5, acc.data_ptr(), stream=stream.cuda_stream, sample_begin=5 * k, seed=13)
+    torch.cuda.synchronize()
+    for sc, cam, stream, acc, alone in jobs:
+        assert torch.equal(acc, alone)
+        sc.close()
