@@ -65,13 +65,38 @@ inline rt_scene_desc *load(const char *path) {
         fclose(f);
         return nullptr;
     }
-    const size_t sz[9] = {sizeof(rt_prim) * c[0],     sizeof(rt_group) * c[1],
-                          sizeof(rt_material) * c[2], sizeof(rt_texture) * c[3],
-                          sizeof(rt_perlin) * c[4],   sizeof(rt_image) * c[5],
-                          (size_t)c[6],               sizeof(rt_xform_op) * c[7],
-                          sizeof(rt_xform_chain) * c[8]};
-    size_t total = pad8(sizeof(rt_scene_desc));
-    for (int i = 0; i < 9; i++) total += pad8(sz[i]);
+    /* the counts come from the file: every element count must fit the descriptor's int32
+     * fields, no size may wrap, and the arrays together must be what the file actually holds */
+    static const size_t elem[9] = {sizeof(rt_prim),     sizeof(rt_group),   sizeof(rt_material),
+                                   sizeof(rt_texture),  sizeof(rt_perlin),  sizeof(rt_image),
+                                   1,                   sizeof(rt_xform_op), sizeof(rt_xform_chain)};
+    long here = ftell(f);
+    if (here < 0 || fseek(f, 0, SEEK_END) != 0) {
+        fclose(f);
+        return nullptr;
+    }
+    long end = ftell(f);
+    if (end < here || fseek(f, here, SEEK_SET) != 0) {
+        fclose(f);
+        return nullptr;
+    }
+    const uint64_t file_payload = (uint64_t)(end - here);
+    size_t sz[9];
+    uint64_t sum = 0;
+    for (int i = 0; i < 9; i++) {
+        const uint64_t limit = i == 6 ? file_payload : (uint64_t)0x7fffffff;
+        if (c[i] > limit || c[i] > file_payload / elem[i]) { /* (also rules out a wrapping product) */
+            fclose(f);
+            return nullptr;
+        }
+        sz[i] = (size_t)(c[i] * elem[i]);
+        sum += pad8(sz[i]);
+    }
+    if (sum != file_payload) {
+        fclose(f);
+        return nullptr;
+    }
+    size_t total = pad8(sizeof(rt_scene_desc)) + (size_t)sum;
     char *blk = (char *)malloc(total);
     if (!blk) {
         fclose(f);

@@ -13,6 +13,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -39,6 +41,20 @@ int fail(int code, const char *fmt, ...) {
     va_end(ap);
     g_err = buf;
     return code;
+}
+
+// No C++ exception may cross the C ABI: bad_alloc / length_error from the host-side containers
+// become error codes.
+template <class F> int guarded(const char *what, F body) {
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        return fail(RT_ERR_HIP, "%s: out of host memory", what);
+    } catch (const std::exception &e) {
+        return fail(RT_ERR_ARG, "%s: %s", what, e.what());
+    } catch (...) {
+        return fail(RT_ERR_ARG, "%s: unknown failure", what);
+    }
 }
 
 #define RT_HIP(call)                                                                               \
@@ -88,7 +104,6 @@ struct rt_scene {
     int tree_top = 0; // HostScene::n_top: how many leading nodes are the most visited ones
     bool lean = false; // no quads, no noise / image textures: the lean render kernels apply
     LaunchGeom geom; // persistent render kernel: grid, block, LDS bytes, what is staged
-    LaunchGeom pool_geom; // the same for render_pool_bvh (pool_slots = 0: not available)
     // wavefront variant: path-state arrays and queues (allocated on first use)
     void *wf_mem = nullptr;
     unsigned wf_slots = 0;
@@ -122,7 +137,21 @@ int validate(const rt_scene_desc *d) {
     if (!d) return fail(RT_ERR_ARG, "scene descriptor is null");
     if (d->abi_version != RT_AMD_ABI_VERSION)
         return fail(RT_ERR_ARG, "descriptor abi_version %u, library %d", d->abi_version, RT_AMD_ABI_VERSION);
-    if (d->n_prims < 0 || (d->n_prims > 0 && !d->prims)) return fail(RT_ERR_ARG, "bad prims array");
+    // every count non-negative, every non-empty array present
+    const struct {
+        const char *name;
+        long long n;
+        const void *p;
+    } arrays[] = {{"prims", d->n_prims, d->prims},           {"groups", d->n_groups, d->groups},
+                  {"materials", d->n_materials, d->materials}, {"textures", d->n_textures, d->textures},
+                  {"perlins", d->n_perlins, d->perlins},       {"images", d->n_images, d->images},
+                  {"xform_ops", d->n_xform_ops, d->xform_ops}, {"chains", d->n_chains, d->chains}};
+    for (const auto &a : arrays) {
+        if (a.n < 0) return fail(RT_ERR_ARG, "negative count of %s", a.name);
+        if (a.n > 0 && !a.p) return fail(RT_ERR_ARG, "%s: %lld entries but a null array", a.name, a.n);
+    }
+    if (d->n_texel_bytes > 0 && !d->texels) return fail(RT_ERR_ARG, "texels: bytes but a null array");
+    if (d->n_texel_bytes > (1ull << 40)) return fail(RT_ERR_ARG, "texels: too many bytes");
     if (d->n_prims >= (1 << 29)) return fail(RT_ERR_ARG, "too many primitives");
     for (int i = 0; i < d->n_prims; i++) {
         const rt_prim &p = d->prims[i];
@@ -131,6 +160,12 @@ int validate(const rt_scene_desc *d) {
         if (p.material < 0 || p.material >= d->n_materials)
             return fail(RT_ERR_ARG, "prim %d: material %d out of range", i, p.material);
         if (p.xform < -1 || p.xform >= d->n_chains) return fail(RT_ERR_ARG, "prim %d: chain out of range", i);
+    }
+    for (int i = 0; i < d->n_groups; i++) {
+        const rt_group &g = d->groups[i];
+        if ((g.kind != RT_GROUP_LIST && g.kind != RT_GROUP_BVH) || g.first_prim < 0 || g.n_prims < 0 ||
+            (long long)g.first_prim + g.n_prims > d->n_prims)
+            return fail(RT_ERR_ARG, "group %d: bad kind or primitive range", i);
     }
     for (int i = 0; i < d->n_materials; i++) {
         const rt_material &m = d->materials[i];
@@ -149,18 +184,21 @@ int validate(const rt_scene_desc *d) {
             return fail(RT_ERR_ARG, "texture %d: checker child out of range", i);
         if (t.type == RT_TEX_NOISE && (t.perlin < 0 || t.perlin >= d->n_perlins))
             return fail(RT_ERR_ARG, "texture %d: perlin table out of range", i);
-        if (t.type == RT_TEX_IMAGE && t.image >= d->n_images)
+        if (t.type == RT_TEX_IMAGE && (t.image < -1 || t.image >= d->n_images)) // -1: file missing (texture.h:62)
             return fail(RT_ERR_ARG, "texture %d: image out of range", i);
     }
     for (int i = 0; i < d->n_images; i++) {
         const rt_image &im = d->images[i];
-        if (im.width <= 0 || im.height <= 0 ||
-            im.offset + (uint64_t)im.width * im.height * 3 > d->n_texel_bytes)
+        const uint64_t bytes = im.width > 0 && im.height > 0 ? (uint64_t)im.width * (uint64_t)im.height * 3u : 0;
+        if (bytes == 0 || im.offset > d->n_texel_bytes || bytes > d->n_texel_bytes - im.offset)
             return fail(RT_ERR_ARG, "image %d: texels out of range", i);
     }
+    for (int i = 0; i < d->n_xform_ops; i++)
+        if (d->xform_ops[i].type < RT_XF_TRANSLATE || d->xform_ops[i].type > RT_XF_SCALE)
+            return fail(RT_ERR_ARG, "wrapper op %d: unknown type %d", i, d->xform_ops[i].type);
     for (int i = 0; i < d->n_chains; i++) {
         const rt_xform_chain &c = d->chains[i];
-        if (c.first_op < 0 || c.n_ops < 0 || c.first_op + c.n_ops > d->n_xform_ops)
+        if (c.first_op < 0 || c.n_ops < 0 || (long long)c.first_op + c.n_ops > d->n_xform_ops)
             return fail(RT_ERR_ARG, "chain %d: ops out of range", i);
     }
     return RT_OK;
@@ -196,7 +234,6 @@ LaunchGeom choose_geom(rt_scene *s, uint32_t flags) {
     lg.block = block;
     lg.lds_scene = false;
     lg.lds_records = 0;
-    lg.pool_slots = 0;
     int bpc = bpc_target;
     // the render kernels' camera-ray rings (one per wave) come after the stacks if there is room
     const size_t ring_bytes = env_int("RT_AMD_RING", 1) != 0
@@ -247,48 +284,6 @@ LaunchGeom choose_geom(rt_scene *s, uint32_t flags) {
     lg.lds_bytes = (int)(used + (lg.ring ? ring_bytes : 0));
     lg.lds_bytes = std::max(lg.lds_bytes, 16);
     lg.grid = s->n_cu * std::max(bpc, 1);
-    return lg;
-}
-
-// Launch shape of render_pool_bvh: one workgroup of RT_POOL_MAX_THREADS lanes per CU; LDS
-// holds the scene (if it fits), every wave's path slots and lists, and the traversal stacks.
-// pool_slots = 0 in the result: the kernel cannot run for this scene (linear scan).
-LaunchGeom choose_pool_geom(rt_scene *s, uint32_t flags) {
-    LaunchGeom lg;
-    const rtc::DevScene &dv = s->dev;
-    lg.block = std::max(64, std::min(RT_POOL_MAX_THREADS, env_int("RT_AMD_POOL_BLOCK", RT_POOL_MAX_THREADS) / 64 * 64));
-    lg.grid = s->n_cu;
-    lg.lds_scene = false;
-    lg.lds_records = 0;
-    lg.lds_bytes = 16;
-    lg.pool_slots = 0;
-    if (dv.traversal != rtc::TRAV_BVH) return lg;
-    const int n_waves = lg.block / 64;
-    const int levels = s->info.bvh_depth + 1;
-    const size_t geom_bytes = ((size_t)dv.n_slots * dv.slot_f4 + (size_t)dv.n_nodes * 4) * sizeof(f4);
-    const size_t all_bytes = scene_lds_bytes(dv);
-    const bool short_ok = dv.n_nodes < 32768 && dv.n_slots < 16384;
-    const int want = std::max(64, std::min(1024, env_int("RT_AMD_POOL_SLOTS", 128) / 32 * 32));
-    for (int m = want; m >= 64 && lg.pool_slots == 0; m -= 32) {
-        const size_t pools = (size_t)n_waves * m * (RT_POOL_SLOT_F4 * sizeof(f4) + 2 * sizeof(unsigned short));
-        const size_t stack16 = (size_t)levels * lg.block * sizeof(short);
-        const size_t stack32 = (size_t)levels * lg.block * sizeof(int);
-        if (!(flags & RT_SCENE_FORCE_GLOBAL) && short_ok && all_bytes + pools + stack16 <= (size_t)kMaxLdsBytes) {
-            lg.lds_scene = true;
-            lg.lds_records = 1;
-            lg.lds_bytes = (int)(all_bytes + pools + stack16);
-            lg.pool_slots = m;
-        } else if (!(flags & RT_SCENE_FORCE_GLOBAL) && short_ok && m == want &&
-                   geom_bytes + pools + stack16 <= (size_t)kMaxLdsBytes) {
-            lg.lds_scene = true;
-            lg.lds_bytes = (int)(geom_bytes + pools + stack16);
-            lg.pool_slots = m;
-        } else if (((flags & RT_SCENE_FORCE_GLOBAL) || !short_ok || geom_bytes > (size_t)kMaxLdsBytes / 2) &&
-                   pools + stack32 <= (size_t)kMaxLdsBytes) {
-            lg.lds_bytes = (int)(pools + stack32);
-            lg.pool_slots = m;
-        }
-    }
     return lg;
 }
 
@@ -360,7 +355,7 @@ int rt_scene_destroy(rt_scene *s) {
     return RT_OK;
 }
 
-int rt_scene_create(const rt_scene_desc *d, int device, uint32_t flags, rt_scene **out) {
+static int impl_rt_scene_create(const rt_scene_desc *d, int device, uint32_t flags, rt_scene **out) {
     if (!out) return fail(RT_ERR_ARG, "out is null");
     *out = nullptr;
     int rc = validate(d);
@@ -479,19 +474,16 @@ int rt_scene_create(const rt_scene_desc *d, int device, uint32_t flags, rt_scene
     hipError_t e = rtl::set_mega_lds_limit(kMaxLdsBytes);
     if (e == hipSuccess) e = rtl::set_mega_lds_limit_lean(kMaxLdsBytes);
     if (e == hipSuccess) e = rtl::set_wavefront_lds_limit(kMaxLdsBytes);
-    if (e == hipSuccess) e = rtl::set_pool_lds_limit(kMaxLdsBytes);
     if (e != hipSuccess) {
         rt_scene_destroy(s);
         return fail(RT_ERR_HIP, "cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
     }
 
     s->geom = choose_geom(s, flags);
-    s->pool_geom = choose_pool_geom(s, flags);
     if (env_int("RT_AMD_DEBUG", 0))
-        fprintf(stderr, "librt_amd: render geometry grid %d block %d lds %d (scene %d records %d), resident blocks/CU %d; pool: block %d lds %d slots %d\n",
+        fprintf(stderr, "librt_amd: render geometry grid %d block %d lds %d (scene %d records %d), resident blocks/CU %d\n",
                 s->geom.grid, s->geom.block, s->geom.lds_bytes, (int)s->geom.lds_scene, s->geom.lds_records,
-                rtl::mega_blocks_per_cu(s->geom.block, s->geom.lds_bytes, s->geom.lds_scene), s->pool_geom.block,
-                s->pool_geom.lds_bytes, s->pool_geom.pool_slots);
+                rtl::mega_blocks_per_cu(s->geom.block, s->geom.lds_bytes, s->geom.lds_scene));
     s->info.lds_resident = s->geom.lds_scene ? 1 : 0;
     *out = s;
     return RT_OK;
@@ -550,35 +542,105 @@ int ensure_wavefront(rt_scene *s, unsigned n_slots) {
     return RT_OK;
 }
 
-} // namespace
+// Knobs of the render kernels' scheduling, read from the environment once per call.
+struct Tunables {
+    int scheduler, pipeline, spill_max, tail_blocks, unit_order, strip_order;
+    int min_ready, leaf_min, blocked_min, regen_min;
+    bool timeline;
+};
+Tunables read_tunables(bool lds_scene) {
+    Tunables t;
+    t.scheduler = env_int("RT_AMD_SCHEDULER", 1) != 0 ? 1 : 0; // BVH scenes: 1 = decoupled (default), 0 = whole ray
+    t.pipeline = env_int("RT_AMD_PIPELINE", 1);
+    t.spill_max = std::max(0, std::min(64, env_int("RT_AMD_SPILL_MAX", 16)));
+    t.tail_blocks = env_int("RT_AMD_TAIL_BLOCKS", 16);
+    t.unit_order = env_int("RT_AMD_UNIT_ORDER", 1);
+    t.strip_order = env_int("RT_AMD_STRIP_ORDER", lds_scene ? 1 : 0);
+    t.min_ready = std::max(1, std::min(64, env_int("RT_AMD_MIN_READY", 40)));
+    t.leaf_min = std::max(1, std::min(64, env_int("RT_AMD_LEAF_MIN", 8)));
+    t.blocked_min = std::max(1, std::min(64, env_int("RT_AMD_BLOCKED_MIN", 2)));
+    t.regen_min = std::max(1, std::min(64, env_int("RT_AMD_REGEN_MIN", 1)));
+    t.timeline = getenv("RT_AMD_TIMELINE") != nullptr;
+    return t;
+}
 
-extern "C" {
+// The fields of RenderParams every launch has: image, sample range, units, scheduling knobs.
+// Everything optional (strip order, tail hand-over, counters, timeline) starts switched off.
+RenderParams base_params(int W, int H, int n_pixels, const rt_render_opts *opts, int done, int sc_n,
+                                const LaunchGeom &lg, const Tunables &tn) {
+    RenderParams rp;
+    memset(&rp, 0, sizeof(rp));
+    rp.width = W;
+    rp.height = H;
+    rp.n_pixels = n_pixels;
+    rp.sample_begin = opts->sample_begin + done;
+    rp.sample_count = sc_n;
+    rp.seed = opts->seed;
+    rp.n_strips = (unsigned)((n_pixels + 63) / 64);
+    rp.n_units = rp.n_strips * (unsigned)sc_n;
+    rp.pixel_major = tn.unit_order;
+    rp.ring_f4 = lg.ring_f4;
+    rp.scheduler = tn.scheduler;
+    rp.min_ready = tn.min_ready;
+    rp.leaf_min = tn.leaf_min;
+    rp.blocked_min = tn.blocked_min;
+    rp.regen_min = tn.regen_min;
+    return rp;
+}
 
-int rt_render_device(rt_scene *s, const rt_camera_desc *cam, const rt_render_opts *opts, float *d_accum,
-                     void *stream_v, rt_render_stats *stats) {
-    if (!s || !cam || !opts || !d_accum) return fail(RT_ERR_ARG, "null argument");
+// Checks shared by the render entry points; fills the device camera.
+int check_render_args(rt_scene *s, const rt_camera_desc *cam, const rt_render_opts *opts, rtc::DevCamera &dc,
+                             int &n_pixels) {
     if (opts->sample_count < 0 || opts->sample_begin < 0) return fail(RT_ERR_ARG, "negative sample range");
-    if (opts->mode != RT_MODE_MEGAKERNEL && opts->mode != RT_MODE_WAVEFRONT)
-        return fail(RT_ERR_UNSUPPORTED, "render mode %d not available", opts->mode);
-    const bool wavefront = opts->mode == RT_MODE_WAVEFRONT;
-    if (wavefront && (opts->flags & RT_RENDER_COUNTERS))
-        return fail(RT_ERR_UNSUPPORTED, "the wavefront variant has no instrumented build");
+    if ((long long)opts->sample_begin + opts->sample_count > 0x7fffffffll) return fail(RT_ERR_ARG, "sample range overflows");
     if (cam->max_depth < 0) return fail(RT_ERR_ARG, "negative max_depth");
+    // paths handed from wave to wave and the wavefront variant keep the bounces left in 16 bits
+    if (cam->max_depth > 65535) return fail(RT_ERR_ARG, "max_depth %d: at most 65535", cam->max_depth);
     int rc = set_device(s->device);
     if (rc != RT_OK) return rc;
-    hipStream_t stream = (hipStream_t)stream_v;
-
-    rtc::DevCamera dc;
     rc = rt_camera_initialize(cam, &dc.f);
     if (rc != RT_OK) return rc;
     for (int k = 0; k < 3; k++) dc.background[k] = cam->background[k];
     dc.defocus_angle = cam->defocus_angle;
     dc.max_depth = cam->max_depth;
-
-    const int W = dc.f.image_width, H = dc.f.image_height;
-    const long long n_pixels_ll = (long long)W * H;
+    const long long n_pixels_ll = (long long)dc.f.image_width * dc.f.image_height;
     if (n_pixels_ll > (1ll << 30)) return fail(RT_ERR_ARG, "image too large");
-    const int n_pixels = (int)n_pixels_ll;
+    n_pixels = (int)n_pixels_ll;
+    return RT_OK;
+}
+
+struct EventPair { // destroyed on every way out of the function that made them
+    hipEvent_t a = nullptr, b = nullptr;
+    int create() {
+        RT_HIP(hipEventCreate(&a));
+        RT_HIP(hipEventCreate(&b));
+        return RT_OK;
+    }
+    void release() { a = b = nullptr; }
+    ~EventPair() {
+        if (a) hipEventDestroy(a);
+        if (b) hipEventDestroy(b);
+    }
+};
+
+} // namespace
+
+extern "C" {
+
+static int impl_rt_render_device(rt_scene *s, const rt_camera_desc *cam, const rt_render_opts *opts, float *d_accum,
+                     void *stream_v, rt_render_stats *stats) {
+    if (!s || !cam || !opts || !d_accum) return fail(RT_ERR_ARG, "null argument");
+    if (opts->mode != RT_MODE_MEGAKERNEL && opts->mode != RT_MODE_WAVEFRONT)
+        return fail(RT_ERR_UNSUPPORTED, "render mode %d not available", opts->mode);
+    const bool wavefront = opts->mode == RT_MODE_WAVEFRONT;
+    if (wavefront && (opts->flags & RT_RENDER_COUNTERS))
+        return fail(RT_ERR_UNSUPPORTED, "the wavefront variant has no instrumented build");
+    rtc::DevCamera dc;
+    int n_pixels = 0;
+    int rc = check_render_args(s, cam, opts, dc, n_pixels);
+    if (rc != RT_OK) return rc;
+    hipStream_t stream = (hipStream_t)stream_v;
+    const int W = dc.f.image_width, H = dc.f.image_height;
 
     if (stats) {
         memset(stats, 0, sizeof(*stats));
@@ -605,10 +667,9 @@ int rt_render_device(rt_scene *s, const rt_camera_desc *cam, const rt_render_opt
     };
 
     const bool count = (opts->flags & RT_RENDER_COUNTERS) != 0 && stats != nullptr;
-    // BVH scenes: 1 = decoupled (default), 0 = whole ray, 2 = path pool in LDS (experimental)
-    int scheduler = env_int("RT_AMD_SCHEDULER", 1);
-    if (scheduler == 2 && (s->pool_geom.pool_slots == 0 || wavefront)) scheduler = 1;
-    const LaunchGeom lg = scheduler == 2 ? s->pool_geom : s->geom;
+    const LaunchGeom lg = s->geom;
+    const Tunables tn = read_tunables(lg.lds_scene);
+    const int scheduler = tn.scheduler;
     rtc::DevScene dev = s->dev;
     dev.lds_records = lg.lds_records;
     unsigned wf_slots = 0;
@@ -621,10 +682,10 @@ int rt_render_device(rt_scene *s, const rt_camera_desc *cam, const rt_render_opt
         rc = ensure_wavefront(s, wf_slots);
         if (rc != RT_OK) return rc;
     }
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    EventPair ev; // brackets each launch on the caller's stream when statistics are wanted
     if (stats) {
-        RT_HIP(hipEventCreate(&ev0));
-        RT_HIP(hipEventCreate(&ev1));
+        rc = ev.create();
+        if (rc != RT_OK) return rc;
         RT_HIP(hipMemsetAsync(s->d_words + 1, 0, sizeof(unsigned long long), stream));
         if (count) {
             rtc::Counters zero;
@@ -635,8 +696,7 @@ int rt_render_device(rt_scene *s, const rt_camera_desc *cam, const rt_render_opt
         }
     }
     // pipelined launches: megakernel only, and not when the caller wants per-call statistics
-    const bool pipelined = !wavefront && scheduler != 2 && !stats && !(opts->flags & RT_RENDER_NO_OVERLAP) &&
-                           env_int("RT_AMD_PIPELINE", 1) != 0;
+    const bool pipelined = !wavefront && !stats && !(opts->flags & RT_RENDER_NO_OVERLAP) && tn.pipeline != 0;
     float mega_ms = 0.0f;
     for (int done = 0; done < opts->sample_count; done += chunk) {
         int sc_n = std::min(chunk, opts->sample_count - done);
@@ -644,16 +704,17 @@ int rt_render_device(rt_scene *s, const rt_camera_desc *cam, const rt_render_opt
         if (pipelined) s->flip ^= 1;
         rc = ensure_stage(b);
         if (rc != RT_OK) return rc;
+        // every launch leaves an event behind that says "this record set has been reduced"
+        if (!s->ev_free[b]) RT_HIP(hipEventCreateWithFlags(&s->ev_free[b], hipEventDisableTiming));
         hipStream_t ms = stream; // the stream the render kernel goes to
         if (pipelined) {
             if (!s->mega_stream[b]) {
                 RT_HIP(hipStreamCreateWithFlags(&s->mega_stream[b], hipStreamNonBlocking));
                 RT_HIP(hipEventCreateWithFlags(&s->ev_done[b], hipEventDisableTiming));
-                RT_HIP(hipEventCreateWithFlags(&s->ev_free[b], hipEventDisableTiming));
             }
             ms = s->mega_stream[b];
             // tail hand-over: only BVH scenes with the decoupled scheduler have it
-            const int want_spill = std::max(0, std::min(64, env_int("RT_AMD_SPILL_MAX", 16)));
+            const int want_spill = tn.spill_max;
             const int waves = lg.grid * (lg.block / 64);
             if (want_spill > 0 && s->dev.traversal == rtc::TRAV_BVH && scheduler == 1 &&
                 (s->spill_waves < waves || s->spill_max < want_spill)) {
@@ -670,28 +731,20 @@ int rt_render_device(rt_scene *s, const rt_camera_desc *cam, const rt_render_opt
                 s->spill_max = want_spill;
                 s->epoch = 0;
             }
-            // this set's previous records must have been reduced; nothing else orders the
-            // render kernel (it reads only the scene and writes only this set)
+            // this set's previous records must have been reduced (by a pipelined call or by one
+            // that kept to its caller's stream); nothing else orders the render kernel (it reads
+            // only the scene and writes only this set)
             if (s->ev_free_valid[b]) RT_HIP(hipStreamWaitEvent(ms, s->ev_free[b], 0));
-        } else if (s->ev_free_valid[0] || s->ev_free_valid[1]) {
-            // a non-pipelined launch after pipelined ones reuses set 0 on the caller's stream
+        } else {
+            // set 0 on the caller's stream: whatever used either set last must be through with it
+            // (set 1 too: the strip costs and the ray counter are shared with it)
             for (int k = 0; k < 2; k++)
                 if (s->ev_free_valid[k]) RT_HIP(hipStreamWaitEvent(stream, s->ev_free[k], 0));
         }
-        RenderParams rp;
-        rp.width = W;
-        rp.height = H;
-        rp.n_pixels = n_pixels;
-        rp.sample_begin = opts->sample_begin + done;
-        rp.sample_count = sc_n;
-        rp.seed = opts->seed;
-        rp.n_strips = (unsigned)((n_pixels + 63) / 64);
-        rp.n_units = rp.n_strips * (unsigned)sc_n;
-        rp.pixel_major = env_int("RT_AMD_UNIT_ORDER", 1);
+        RenderParams rp = base_params(W, H, n_pixels, opts, done, sc_n, lg, tn);
         // Strips in the order of their cost in this set's previous launch (megakernel, scenes in
         // LDS: for scenes read from HBM neighbouring rays matter more than the tail of the launch)
-        const bool strip_costs = !wavefront && rp.pixel_major && env_int("RT_AMD_STRIP_ORDER", lg.lds_scene ? 1 : 0) != 0;
-        rp.strip_order = nullptr;
+        const bool strip_costs = !wavefront && rp.pixel_major && tn.strip_order != 0;
         if (strip_costs) {
             if (rp.n_strips > s->strip_cap) {
                 RT_HIP(hipDeviceSynchronize());
@@ -718,20 +771,12 @@ int rt_render_device(rt_scene *s, const rt_camera_desc *cam, const rt_render_opt
             }
             if (s->strip_valid[b] == rp.n_strips) rp.strip_order = s->strip_order[b];
         }
-        rp.ring_f4 = lg.ring_f4;
         rp.stage = s->stage[b];
         rp.next_chunk = reinterpret_cast<unsigned *>(s->d_words + 2 * b); // words 0 / 2: pool counters, 1: rays
         rp.counters = count ? s->d_counters : nullptr;
-        rp.scheduler = scheduler;
-        rp.spill = nullptr;
-        rp.spill_count = nullptr;
-        rp.next_batch = nullptr;
-        rp.epoch = 0;
-        rp.spill_max = 0;
-        rp.n_server_blocks = 0;
         if (pipelined && s->spill[b] && s->dev.traversal == rtc::TRAV_BVH && scheduler == 1) {
-            const int servers = std::max(1, std::min(lg.grid / 4, env_int("RT_AMD_TAIL_BLOCKS", 16)));
-            const int want_spill = std::max(0, std::min(s->spill_max, env_int("RT_AMD_SPILL_MAX", 16)));
+            const int servers = std::max(1, std::min(lg.grid / 4, tn.tail_blocks));
+            const int want_spill = std::min(s->spill_max, tn.spill_max);
             if (want_spill > 0 && lg.grid > servers) {
                 s->epoch = (s->epoch + 1) & 0xffffffu;
                 if (s->epoch == 0) s->epoch = 1;
@@ -744,8 +789,7 @@ int rt_render_device(rt_scene *s, const rt_camera_desc *cam, const rt_render_opt
                 RT_HIP(hipMemsetAsync(s->d_words + 4 + b, 0, sizeof(unsigned long long), ms));
             }
         }
-        rp.timeline = nullptr;
-        if (!wavefront && scheduler == 1 && s->dev.traversal == rtc::TRAV_BVH && getenv("RT_AMD_TIMELINE")) {
+        if (!wavefront && scheduler == 1 && s->dev.traversal == rtc::TRAV_BVH && tn.timeline) {
             const int waves = lg.grid * (lg.block / 64);
             if (!s->d_timeline) {
                 RT_HIP(hipMalloc((void **)&s->d_timeline, (size_t)kTimelineLaunches * waves * 32));
@@ -756,24 +800,16 @@ int rt_render_device(rt_scene *s, const rt_camera_desc *cam, const rt_render_opt
             if (waves == s->timeline_waves)
                 rp.timeline = s->d_timeline + (size_t)(s->timeline_launches++ % kTimelineLaunches) * waves * 4;
         }
-        rp.pool_slots = lg.pool_slots;
-        rp.dispatch_min = std::max(1, std::min(64, env_int("RT_AMD_DISPATCH_MIN", 8)));
-        rp.min_ready = std::max(1, std::min(64, env_int("RT_AMD_MIN_READY", 40)));
-        rp.leaf_min = std::max(1, std::min(64, env_int("RT_AMD_LEAF_MIN", 8)));
-        rp.blocked_min = std::max(1, std::min(64, env_int("RT_AMD_BLOCKED_MIN", 2)));
-        rp.regen_min = std::max(1, std::min(64, env_int("RT_AMD_REGEN_MIN", 1)));
         RT_HIP(hipMemsetAsync(s->d_words + 2 * b, 0, sizeof(unsigned long long), ms));
-        hipEvent_t p0 = nullptr, p1 = nullptr;
+        EventPair prof;
         if (s->profiling) {
-            RT_HIP(hipEventCreate(&p0));
-            RT_HIP(hipEventCreate(&p1));
-            RT_HIP(hipEventRecord(p0, ms));
+            rc = prof.create();
+            if (rc != RT_OK) return rc;
+            RT_HIP(hipEventRecord(prof.a, ms));
         }
-        if (stats) RT_HIP(hipEventRecord(ev0, stream));
+        if (stats) RT_HIP(hipEventRecord(ev.a, stream));
         if (!wavefront) {
-            if (scheduler == 2)
-                RT_HIP(rtl::launch_pool(dev, dc, rp, lg, ms));
-            else if (s->lean)
+            if (s->lean)
                 RT_HIP(rtl::launch_mega_lean(dev, dc, rp, lg, ms));
             else
                 RT_HIP(rtl::launch_mega(dev, dc, rp, lg, ms));
@@ -784,11 +820,12 @@ int rt_render_device(rt_scene *s, const rt_camera_desc *cam, const rt_render_opt
             RT_HIP(rtl::render_wavefront(dev, dc, rp, s->wf, wf_slots, lg, s->wf_host_cnt, stream, &rounds));
             wf_rounds += rounds;
         }
-        if (stats) RT_HIP(hipEventRecord(ev1, stream));
+        if (stats) RT_HIP(hipEventRecord(ev.b, stream));
         if (s->profiling) {
-            RT_HIP(hipEventRecord(p1, ms));
-            s->prof_events.push_back(p0);
-            s->prof_events.push_back(p1);
+            RT_HIP(hipEventRecord(prof.b, ms));
+            s->prof_events.push_back(prof.a);
+            s->prof_events.push_back(prof.b);
+            prof.release(); // rt_profile_end destroys them
         }
         if (pipelined) { // the caller's stream takes over once the records are complete
             RT_HIP(hipEventRecord(s->ev_done[b], ms));
@@ -796,26 +833,23 @@ int rt_render_device(rt_scene *s, const rt_camera_desc *cam, const rt_render_opt
         }
         RT_HIP(rtl::launch_reduce(s->stage[b], n_pixels, sc_n, d_accum, s->d_words + 1,
                                   strip_costs ? s->strip_cost[b] : nullptr, stream));
-        if (strip_costs) { // the set's next launch waits for ev_free (pipelined) or follows on this stream
+        if (strip_costs) { // the set's next launch waits for ev_free
             RT_HIP(rtl::order_strips(s->strip_cost[b], s->strip_iota, rp.n_strips, s->strip_sorted, s->strip_order[b],
                                      s->strip_tmp, s->strip_tmp_bytes, stream));
             s->strip_valid[b] = rp.n_strips;
         }
-        if (pipelined) {
-            RT_HIP(hipEventRecord(s->ev_free[b], stream));
-            s->ev_free_valid[b] = true;
-        }
+        // whoever uses this set next (on whatever stream) waits for this
+        RT_HIP(hipEventRecord(s->ev_free[b], stream));
+        s->ev_free_valid[b] = true;
         if (stats) {
-            RT_HIP(hipEventSynchronize(ev1));
-            float ms = 0.0f;
-            RT_HIP(hipEventElapsedTime(&ms, ev0, ev1));
-            mega_ms += ms;
+            RT_HIP(hipEventSynchronize(ev.b));
+            float ms_f = 0.0f;
+            RT_HIP(hipEventElapsedTime(&ms_f, ev.a, ev.b));
+            mega_ms += ms_f;
         }
     }
     if (stats) {
         RT_HIP(hipStreamSynchronize(stream));
-        hipEventDestroy(ev0);
-        hipEventDestroy(ev1);
         unsigned long long rays = 0;
         RT_HIP(hipMemcpy(&rays, s->d_words + 1, sizeof(rays), hipMemcpyDeviceToHost));
         stats->paths = (uint64_t)n_pixels * (uint64_t)opts->sample_count;
@@ -1096,9 +1130,17 @@ int rt_scene_file_save(const rt_scene_desc *desc, const char *path) {
 int rt_scene_file_load(const char *path, rt_scene_desc **out) {
     if (!path || !out) return fail(RT_ERR_ARG, "null argument");
     *out = rtio::load(path);
-    if (!*out) return fail(RT_ERR_IO, "cannot read %s", path);
+    if (!*out) return fail(RT_ERR_IO, "cannot read %s (missing, truncated or inconsistent counts)", path);
     return RT_OK;
 }
 void rt_scene_file_free(rt_scene_desc *desc) { free(desc); }
 
 } // extern "C"
+
+extern "C" int rt_scene_create(const rt_scene_desc *d, int device, uint32_t flags, rt_scene **out) {
+    return guarded("rt_scene_create", [&] { return impl_rt_scene_create(d, device, flags, out); });
+}
+
+extern "C" int rt_render_device(rt_scene *s, const rt_camera_desc *cam, const rt_render_opts *opts, float *d_accum, void *stream_v, rt_render_stats *stats) {
+    return guarded("rt_render_device", [&] { return impl_rt_render_device(s, cam, opts, d_accum, stream_v, stats); });
+}

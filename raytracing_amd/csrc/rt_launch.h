@@ -10,9 +10,6 @@
 #define RT_MEGA_WAVES_PER_SIMD 4
 #endif
 #define RT_TRACE_THREADS 256
-#define RT_POOL_MAX_THREADS 512  // render_pool_bvh: 2 waves per SIMD, up to 256 VGPRs
-#define RT_POOL_WAVES_PER_SIMD 2
-#define RT_POOL_SLOT_F4 5        // 80-byte path slots of render_pool_bvh
 #define RT_SPILL_F4 5            // 80-byte records of paths handed over at the tail of a launch
 #ifndef RT_POOL_MAX_UNITS
 #define RT_POOL_MAX_UNITS 32u // a workgroup reserves at most this many units of 64 paths at a time
@@ -21,7 +18,6 @@
 #define RT_POOL_GUIDE_DIV 2u // ... and at most 1/RT_POOL_GUIDE_DIV of its share of what is left
 #endif
 #define RT_BLOCK_POOL_BYTES 64 // static LDS of the render kernels besides the dynamic part
-
 struct RenderParams {
     int width, height, n_pixels;
     int sample_begin; // global index of the first sample of this launch
@@ -53,8 +49,6 @@ struct RenderParams {
     // Debugging aid (non-null): every wave of the decoupled kernel leaves {start, out of new
     // paths, exit} in 100 MHz wall-clock ticks and its hardware id, 4 x 8 bytes per wave.
     unsigned long long *timeline;
-    int pool_slots;   // path pool: path slots per wave (LDS)
-    int dispatch_min; // path pool: idle engines that must accumulate before pending rays are handed out
 };
 
 struct LaunchGeom {
@@ -62,7 +56,6 @@ struct LaunchGeom {
     int lds_bytes;
     bool lds_scene;  // slots + nodes are staged into LDS
     int lds_records; // ... and so are the per-slot records and the texture table
-    int pool_slots;  // render_pool_bvh: path slots per wave (0: this geometry is not for it)
     // decoupled kernel: every wave keeps the 64 camera rays of its current unit in LDS (generated
     // by all lanes at once when the unit is taken; idle lanes then only fetch theirs)
     bool ring = false;
@@ -95,9 +88,6 @@ hipError_t set_mega_lds_limit(int bytes);
 hipError_t launch_mega_lean(const rtc::DevScene &sc, const rtc::DevCamera &cam, const RenderParams &rp,
                             const LaunchGeom &lg, hipStream_t stream);
 hipError_t set_mega_lds_limit_lean(int bytes);
-hipError_t launch_pool(const rtc::DevScene &sc, const rtc::DevCamera &cam, const RenderParams &rp,
-                       const LaunchGeom &lg, hipStream_t stream);
-hipError_t set_pool_lds_limit(int bytes);
 int mega_waves_per_simd(); // register budget the render kernels were compiled for
 int mega_blocks_per_cu(int block, int lds_bytes, bool lds_scene);
 hipError_t launch_reduce(const rtc::f4 *stage, int n_pixels, int sample_count, float *accum,

@@ -91,6 +91,70 @@ def test_descriptor_validation():
     assert e.value.code == abi.RT_ERR_ARG and "material" in str(e.value)
 
 
+def test_descriptor_validation_rejects_malformed_counts_and_arrays():
+    """Negative counts, null arrays with a positive count, unknown wrapper ops and image indices
+    below -1 are refused before anything is copied (the checks run ahead of the device check)."""
+    arrays, cam, _ = load_scene("cornell_box")
+    h = C.c_void_p()
+
+    def create(d):
+        return binding.lib().rt_scene_create(C.byref(d), 0, 0, C.byref(h))
+
+    for field in ("n_prims", "n_groups", "n_materials", "n_textures", "n_perlins", "n_images", "n_xform_ops",
+                  "n_chains"):
+        d = arrays.desc()
+        setattr(d, field, -3)
+        assert create(d) == abi.RT_ERR_ARG, field
+        assert b"negative" in binding.lib().rt_last_error()
+    for field in ("prims", "materials", "textures", "xform_ops", "chains"):
+        d = arrays.desc()
+        setattr(d, field, None)
+        assert create(d) == abi.RT_ERR_ARG, field
+        assert b"null array" in binding.lib().rt_last_error()
+    bad = abi.SceneArrays(prims=arrays.prims, materials=arrays.materials, textures=arrays.textures,
+                          xform_ops=arrays.xform_ops.copy(), chains=arrays.chains)
+    bad.xform_ops["type"][0] = 7
+    assert create(bad.desc()) == abi.RT_ERR_ARG and b"wrapper op" in binding.lib().rt_last_error()
+    bad = abi.SceneArrays(prims=arrays.prims, materials=arrays.materials, textures=arrays.textures,
+                          xform_ops=arrays.xform_ops, chains=arrays.chains.copy())
+    bad.chains["first_op"][1] = 2**31 - 1  # first_op + n_ops would wrap in 32 bits
+    assert create(bad.desc()) == abi.RT_ERR_ARG and b"chain" in binding.lib().rt_last_error()
+    e_arrays, _, _ = load_scene("earth")
+    bad = abi.SceneArrays(prims=e_arrays.prims, materials=e_arrays.materials, textures=e_arrays.textures.copy(),
+                          images=e_arrays.images, texels=e_arrays.texels)
+    k = int(np.nonzero(bad.textures["type"] == abi.RT_TEX_IMAGE)[0][0])
+    bad.textures["image"][k] = -2
+    assert create(bad.desc()) == abi.RT_ERR_ARG and b"image" in binding.lib().rt_last_error()
+    bad.textures["image"][k] = 0
+    bad.images = e_arrays.images.copy()
+    bad.images["offset"][0] = 2**63  # offset + size would wrap in 64 bits
+    assert create(bad.desc()) == abi.RT_ERR_ARG and b"texels" in binding.lib().rt_last_error()
+
+
+def test_scene_file_with_inconsistent_counts_is_refused(tmp_path):
+    """The counts in a .rtscene header are checked against the file before anything is
+    allocated: wrapping sizes, counts beyond int32 and truncated files all fail to load."""
+    blob = bytearray(open(os.path.join(GOLDEN, "quads.rtscene"), "rb").read())
+    out = C.POINTER(abi.SceneDesc)()
+
+    def load(b):
+        p = str(tmp_path / "bad.rtscene")
+        open(p, "wb").write(bytes(b))
+        return binding.lib().rt_scene_file_load(p.encode(), C.byref(out))
+
+    assert load(blob) == abi.RT_OK
+    binding.lib().rt_scene_file_free(out)
+    for slot, value in ((0, 2**64 // 64 + 5),  # sizeof(rt_prim) * count wraps to a small number
+                        (2, 2**32 + 5),        # would be truncated to 5 in the int32 field
+                        (6, 2**62),            # texel bytes far beyond the file
+                        (1, 2**31)):
+        b = bytearray(blob)
+        b[8 + 8 * slot:16 + 8 * slot] = int(value).to_bytes(8, "little")
+        assert load(b) == abi.RT_ERR_IO, slot
+    assert load(blob[:-8]) == abi.RT_ERR_IO   # truncated
+    assert load(blob + b"\0" * 8) == abi.RT_ERR_IO  # trailing bytes the counts do not account for
+
+
 # ---- kernel logic on the host (same headers the HIP kernels are built from) -------------------
 
 @pytest.mark.parametrize("scene", SCENES)

@@ -74,9 +74,9 @@ def test_wavefront_rejects_counters():
 
 
 def test_schedulers_and_kernel_variants_agree(monkeypatch):
-    """BVH scenes can be rendered by three persistent kernels (RT_AMD_SCHEDULER: 0 whole ray,
-    1 decoupled, 2 path pool in LDS), each in a full and a lean build (the latter without
-    the quad / noise / image branches, chosen for scenes that have none of them): all six
+    """BVH scenes can be rendered by two persistent kernels (RT_AMD_SCHEDULER: 0 whole ray,
+    1 decoupled), each in a full and a lean build (the latter without
+    the quad / noise / image branches, chosen for scenes that have none of them): all four
     run the same per-ray code and must give the same image bit for bit."""
     B = _binding()
     arrays, cam, _ = load_scene("bouncing_spheres")
@@ -85,7 +85,7 @@ def test_schedulers_and_kernel_variants_agree(monkeypatch):
     for no_lean in ("0", "1"):
         monkeypatch.setenv("RT_AMD_NO_LEAN", no_lean)   # read by rt_scene_create
         sc = B.Scene(arrays)
-        for sched in ("0", "1", "2"):
+        for sched in ("0", "1"):
             monkeypatch.setenv("RT_AMD_SCHEDULER", sched)  # read by rt_render
             acc, st = sc.render(cam, 6, seed=9)
             images.append((no_lean, sched, acc, st.rays))
