@@ -278,6 +278,22 @@ int rt_render(rt_scene *scene, const rt_camera_desc *cam, const rt_render_opts *
 int rt_render_device(rt_scene *scene, const rt_camera_desc *cam, const rt_render_opts *opts,
                      float *d_accum, void *stream, rt_render_stats *stats);
 
+/* No counterpart in the reference.  rt_render_device for callers that cannot allocate device
+ * memory: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.
+ * The launch's scratch (pool / ray counters and the per-path radiance records) lives in one
+ * statically allocated block of device memory inside the library instead of buffers owned by
+ * the scene: this call makes no hipMalloc / hipFree and creates no streams or events;
+ * everything is enqueued on `stream`.  Megakernel mode only, no statistics
+ * (opts->flags must not have RT_RENDER_COUNTERS).
+ * Limit: image_width * image_height <= RT_STATIC_MAX_PIXELS, else RT_ERR_ARG (larger sample
+ * counts are split into several launches).  Every GPU holds one such block (64 MiB + 4 KiB)
+ * from the first rt_scene_create on it until the process ends.  All calls on one GPU share
+ * that GPU's block, whatever the scene or stream: calls that overlap on one GPU race — order
+ * them on one stream, or synchronise between them.  Same image as rt_render_device. */
+#define RT_STATIC_MAX_PIXELS (4 << 20)
+int rt_render_device_static(rt_scene *scene, const rt_camera_desc *cam, const rt_render_opts *opts,
+                            float *d_accum, void *stream);
+
 /* write_color / linear_to_gamma (color.h:11-32): rgb8 = int(256*clamp(sqrt(scale*c),0,0.999)). */
 int rt_tonemap_u8(const float *accum, int64_t n_pixels, float scale, uint8_t *rgb8);
 /* The same on the device: d_accum and d_rgb8 are device pointers on `device`, the kernel is

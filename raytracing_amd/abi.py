@@ -19,6 +19,7 @@ RT_PRIM_FLAG_MOVING = 1
 RT_MODE_MEGAKERNEL, RT_MODE_WAVEFRONT = 0, 1
 RT_RENDER_COUNTERS = 1
 RT_RENDER_NO_OVERLAP = 2
+RT_STATIC_MAX_PIXELS = 4 << 20  # rt_render_device_static: largest image (pixels)
 RT_SCENE_FORCE_BVH, RT_SCENE_FORCE_LINEAR, RT_SCENE_FORCE_GLOBAL, RT_SCENE_BUILD_DEVICE = 1, 2, 4, 8
 
 f3 = C.c_float * 3

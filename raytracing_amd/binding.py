@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(os.path.dirname(os.path.
 # every symbol include/rt_amd.h declares
 EXPORTS = ["rt_last_error", "rt_abi_version", "rt_device_count", "rt_camera_initialize",
            "rt_scene_create", "rt_scene_destroy", "rt_scene_get_info", "rt_scene_read_nodes", "rt_trace_batch",
-           "rt_trace_batch_device", "rt_render", "rt_render_device", "rt_tonemap_u8", "rt_tonemap_u8_device",
+           "rt_trace_batch_device", "rt_render", "rt_render_device", "rt_render_device_static", "rt_tonemap_u8", "rt_tonemap_u8_device",
            "rt_film_create", "rt_film_destroy", "rt_film_render", "rt_film_snapshot", "rt_film_wait",
            "rt_film_upload", "rt_profile_begin", "rt_profile_end", "rt_scene_file_save", "rt_scene_file_load",
            "rt_scene_file_free"]
@@ -55,6 +55,8 @@ def lib():
         L.rt_render_device.argtypes = [C.c_void_p, C.POINTER(abi.CameraDesc),
                                        C.POINTER(abi.RenderOpts), C.c_void_p, C.c_void_p,
                                        C.POINTER(abi.RenderStats)]
+        L.rt_render_device_static.argtypes = [C.c_void_p, C.POINTER(abi.CameraDesc),
+                                              C.POINTER(abi.RenderOpts), C.c_void_p, C.c_void_p]
         L.rt_tonemap_u8.argtypes = [C.c_void_p, C.c_int64, C.c_float, C.c_void_p]
         L.rt_tonemap_u8_device.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p]
         if hasattr(L, "rt_film_create"):  # (older builds of the library, loaded through RT_AMD_LIB for A/B runs, lack it)
@@ -160,6 +162,13 @@ class Scene:
         check(lib().rt_render_device(self.handle, C.byref(cam), C.byref(o), C.c_void_p(d_accum_ptr),
                                      C.c_void_p(stream), C.byref(st) if st is not None else None))
         return st
+
+    def render_device_static(self, cam, sample_count, d_accum_ptr, stream=0, sample_begin=0, seed=0):
+        """rt_render_device_static: the same render without any device allocation (scratch in the
+        library's static block; image size limited to RT_STATIC_MAX_PIXELS)."""
+        o = abi.RenderOpts(sample_begin, sample_count, seed, abi.RT_MODE_MEGAKERNEL, 0)
+        check(lib().rt_render_device_static(self.handle, C.byref(cam), C.byref(o), C.c_void_p(d_accum_ptr),
+                                            C.c_void_p(stream)))
 
     def profile_begin(self):
         check(lib().rt_profile_begin(self.handle))

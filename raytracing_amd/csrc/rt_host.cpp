@@ -471,12 +471,13 @@ static int impl_rt_scene_create(const rt_scene_desc *d, int device, uint32_t fla
     int n_cu = 0;
     if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n_cu > 0)
         s->n_cu = n_cu;
-    hipError_t e = rtl::set_mega_lds_limit(kMaxLdsBytes);
+    hipError_t e = rtl::static_scratch_setup(device); // this GPU's copy of the block rt_render_device_static uses
+    if (e == hipSuccess) e = rtl::set_mega_lds_limit(kMaxLdsBytes);
     if (e == hipSuccess) e = rtl::set_mega_lds_limit_lean(kMaxLdsBytes);
     if (e == hipSuccess) e = rtl::set_wavefront_lds_limit(kMaxLdsBytes);
     if (e != hipSuccess) {
         rt_scene_destroy(s);
-        return fail(RT_ERR_HIP, "cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+        return fail(RT_ERR_HIP, "kernel set-up (static scratch block, dynamic LDS limit): %s", hipGetErrorString(e));
     }
 
     s->geom = choose_geom(s, flags);
@@ -877,6 +878,57 @@ static int impl_rt_render_device(rt_scene *s, const rt_camera_desc *cam, const r
     return RT_OK;
 }
 
+// rt_render_device for callers that cannot allocate device memory (code under HIP graph
+// capture, serving loops, harnesses that forbid it): the launch's counters and per-path records
+// live in the library's statically allocated block (rt_static.hip) instead of buffers owned by
+// the scene, everything is enqueued on the caller's stream, and nothing here calls hipMalloc /
+// hipFree or creates streams or events.  Megakernel only, no statistics.
+static int impl_rt_render_device_static(rt_scene *s, const rt_camera_desc *cam, const rt_render_opts *opts, float *d_accum,
+                            void *stream_v) {
+    if (!s || !cam || !opts || !d_accum) return fail(RT_ERR_ARG, "null argument");
+    if (opts->mode != RT_MODE_MEGAKERNEL)
+        return fail(RT_ERR_UNSUPPORTED, "rt_render_device_static: megakernel mode only");
+    if (opts->flags & RT_RENDER_COUNTERS) return fail(RT_ERR_UNSUPPORTED, "rt_render_device_static keeps no statistics");
+    rtc::DevCamera dc;
+    int n_pixels = 0;
+    int rc = check_render_args(s, cam, opts, dc, n_pixels);
+    if (rc != RT_OK) return rc;
+    unsigned char *ptr = (unsigned char *)rtl::static_scratch(s->device); // looked up by rt_scene_create
+    if (!ptr) return fail(RT_ERR_HIP, "the static scratch block of device %d was not set up", s->device);
+    if ((unsigned)n_pixels > RT_STATIC_MAX_RECORDS)
+        return fail(RT_ERR_ARG, "rt_render_device_static: an image of %d pixels exceeds the static scratch block "
+                                "(at most %u pixels); use rt_render_device", n_pixels, RT_STATIC_MAX_RECORDS);
+    if (opts->sample_count == 0) return RT_OK;
+    hipStream_t stream = (hipStream_t)stream_v;
+    const int W = dc.f.image_width, H = dc.f.image_height;
+    unsigned long long *words = reinterpret_cast<unsigned long long *>(ptr); // 0: pool counter, 1: rays
+    f4 *stage = reinterpret_cast<f4 *>(ptr + RT_STATIC_HEADER_BYTES);
+
+    int chunk = (int)std::min<size_t>((size_t)opts->sample_count, RT_STATIC_MAX_RECORDS / (size_t)n_pixels);
+    {   // launches of equal size, as rt_render_device does
+        const int n_launches = (opts->sample_count + chunk - 1) / chunk;
+        chunk = (opts->sample_count + n_launches - 1) / n_launches;
+    }
+    const LaunchGeom lg = s->geom;
+    const Tunables tn = read_tunables(lg.lds_scene);
+    rtc::DevScene dev = s->dev;
+    dev.lds_records = lg.lds_records;
+    for (int done = 0; done < opts->sample_count; done += chunk) {
+        const int sc_n = std::min(chunk, opts->sample_count - done);
+        RenderParams rp = base_params(W, H, n_pixels, opts, done, sc_n, lg, tn);
+        rp.stage = stage;
+        rp.next_chunk = reinterpret_cast<unsigned *>(words);
+        // the block keeps the last call's contents: the counters must start at zero
+        RT_HIP(hipMemsetAsync(words, 0, 2 * sizeof(unsigned long long), stream));
+        if (s->lean)
+            RT_HIP(rtl::launch_mega_lean(dev, dc, rp, lg, stream));
+        else
+            RT_HIP(rtl::launch_mega(dev, dc, rp, lg, stream));
+        RT_HIP(rtl::launch_reduce(stage, n_pixels, sc_n, d_accum, words + 1, nullptr, stream));
+    }
+    return RT_OK;
+}
+
 int rt_render(rt_scene *s, const rt_camera_desc *cam, const rt_render_opts *opts, float *accum_host,
               rt_render_stats *stats) {
     if (!s || !cam || !opts || !accum_host) return fail(RT_ERR_ARG, "null argument");
@@ -1143,4 +1195,8 @@ extern "C" int rt_scene_create(const rt_scene_desc *d, int device, uint32_t flag
 
 extern "C" int rt_render_device(rt_scene *s, const rt_camera_desc *cam, const rt_render_opts *opts, float *d_accum, void *stream_v, rt_render_stats *stats) {
     return guarded("rt_render_device", [&] { return impl_rt_render_device(s, cam, opts, d_accum, stream_v, stats); });
+}
+
+extern "C" int rt_render_device_static(rt_scene *s, const rt_camera_desc *cam, const rt_render_opts *opts, float *d_accum, void *stream_v) {
+    return guarded("rt_render_device_static", [&] { return impl_rt_render_device_static(s, cam, opts, d_accum, stream_v); });
 }

@@ -18,6 +18,13 @@
 #define RT_POOL_GUIDE_DIV 2u // ... and at most 1/RT_POOL_GUIDE_DIV of its share of what is left
 #endif
 #define RT_BLOCK_POOL_BYTES 64 // static LDS of the render kernels besides the dynamic part
+// The statically allocated device block behind rt_render_device_static (rt_static.hip): a header
+// of RT_STATIC_HEADER_BYTES (8-byte word 0: the launch's pool counter, word 1: its ray counter)
+// followed by room for RT_STATIC_MAX_RECORDS per-path radiance records of 16 bytes.
+#define RT_STATIC_HEADER_BYTES 4096u
+#define RT_STATIC_MAX_RECORDS (4u << 20)
+#define RT_STATIC_SCRATCH_BYTES (RT_STATIC_HEADER_BYTES + 16u * RT_STATIC_MAX_RECORDS)
+
 struct RenderParams {
     int width, height, n_pixels;
     int sample_begin; // global index of the first sample of this launch
@@ -98,6 +105,8 @@ hipError_t order_strips(const unsigned *cost, const unsigned *iota, unsigned n, 
                         void *tmp, size_t tmp_bytes, hipStream_t stream);
 hipError_t build_lbvh(const float *boxes, const int *types, int n, float **d_nodes_out, int *leaf_order,
                       int *inner_levels);
+hipError_t static_scratch_setup(int device); // the device must be current
+void *static_scratch(int device);
 hipError_t launch_tonemap(const float *accum, long long n_components, float scale, uint8_t *rgb8,
                           hipStream_t stream);
 hipError_t launch_trace(const rtc::DevScene &sc, const rt_ray *rays, long long n, float tmin, float tmax,
