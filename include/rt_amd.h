@@ -223,8 +223,8 @@ typedef struct rt_render_stats {
 
 typedef struct rt_scene_info {
     int32_t n_prims, n_spheres, n_quads;
-    int32_t n_nodes;      /* 0 = linear scan */
-    int32_t bvh_depth;
+    int32_t n_nodes;      /* nodes of the 4-wide tree; 0 = linear scan */
+    int32_t bvh_depth;    /* its inner levels */
     int32_t lds_resident; /* 1 if geometry is staged into LDS by the kernels */
     uint64_t device_bytes;
     float build_ms;       /* flattening + BVH build (host or device), without the upload */
@@ -252,9 +252,11 @@ int rt_camera_initialize(const rt_camera_desc *cam, rt_camera_frame *out);
 int rt_scene_create(const rt_scene_desc *desc, int device, uint32_t flags, rt_scene **out);
 int rt_scene_destroy(rt_scene *scene);
 int rt_scene_get_info(const rt_scene *scene, rt_scene_info *out);
-/* Diagnostic (no counterpart in the reference): copies the scene's BVH nodes back to the host,
- * n_nodes x 64 bytes: {c0.xyz h0.x}{h0.yz c1.xy}{c1.z h1.xyz}{ref0 ref1 - -} with c/h the centre
- * and half extent of the two child boxes; ref >= 0 inner node, ref < 0 leaf ~(slot*2 + type). */
+/* Diagnostic (no counterpart in the reference): copies the nodes of the scene's 4-wide BVH back
+ * to the host, n_nodes x 128 bytes = 32 words: words 6k .. 6k+5 = centre (3) and half extent (3)
+ * of child k's box, words 24..27 = the four child references (int; >= 0 inner node, < 0 leaf
+ * ~(slot*2 + type)), word 28 = number of children (int, 2..4; unused children have an inverted
+ * box), words 29..31 unused. */
 int rt_scene_read_nodes(rt_scene *scene, void *out, uint64_t bytes);
 
 /* Replaces world.hit(r, interval(tmin, tmax), rec) (camera.h:148) for a batch
@@ -264,6 +266,18 @@ int rt_trace_batch(rt_scene *scene, const rt_ray *rays, int64_t n_rays, float tm
 /* Same with device-resident buffers, enqueued on `stream` (a hipStream_t). */
 int rt_trace_batch_device(rt_scene *scene, const rt_ray *d_rays, int64_t n_rays, float tmin,
                           float tmax, rt_hit *d_hits, void *stream);
+
+/* The same query (world.hit, camera.h:148; bvh_node::hit, bvh.h:77-88) answered by the render
+ * kernel's own traversal code: its launch shape, its LDS copy of the scene (or of the top of a
+ * tree that stays in HBM), its stacks and its interleaved scheduling of node steps and parked
+ * leaf tests, with the caller's rays in place of paths.  Same results as rt_trace_batch; it
+ * exists so that the reference's hit records can be checked against the code that renders.
+ * Scenes that are scanned (no tree) have only one closest-hit routine: for them this is
+ * rt_trace_batch. */
+int rt_trace_batch_sched(rt_scene *scene, const rt_ray *rays, int64_t n_rays, float tmin, float tmax,
+                         rt_hit *hits);
+int rt_trace_batch_sched_device(rt_scene *scene, const rt_ray *d_rays, int64_t n_rays, float tmin,
+                                float tmax, rt_hit *d_hits, void *stream);
 
 /* Replaces the sample loop of camera::render (camera.h:40-47) for samples
  * [sample_begin, sample_begin+sample_count) of every pixel: ADDS the radiance

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(os.path.dirname(os.path.
 # every symbol include/rt_amd.h declares
 EXPORTS = ["rt_last_error", "rt_abi_version", "rt_device_count", "rt_camera_initialize",
            "rt_scene_create", "rt_scene_destroy", "rt_scene_get_info", "rt_scene_read_nodes", "rt_trace_batch",
-           "rt_trace_batch_device", "rt_render", "rt_render_device", "rt_render_device_static", "rt_tonemap_u8", "rt_tonemap_u8_device",
+           "rt_trace_batch_device", "rt_trace_batch_sched", "rt_trace_batch_sched_device", "rt_render", "rt_render_device", "rt_render_device_static", "rt_tonemap_u8", "rt_tonemap_u8_device",
            "rt_film_create", "rt_film_destroy", "rt_film_render", "rt_film_snapshot", "rt_film_wait",
            "rt_film_upload", "rt_profile_begin", "rt_profile_end", "rt_scene_file_save", "rt_scene_file_load",
            "rt_scene_file_free"]
@@ -50,6 +50,8 @@ def lib():
                                      C.c_void_p]
         L.rt_trace_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
                                             C.c_void_p, C.c_void_p]
+        L.rt_trace_batch_sched.argtypes = L.rt_trace_batch.argtypes
+        L.rt_trace_batch_sched_device.argtypes = L.rt_trace_batch_device.argtypes
         L.rt_render.argtypes = [C.c_void_p, C.POINTER(abi.CameraDesc), C.POINTER(abi.RenderOpts),
                                 C.c_void_p, C.POINTER(abi.RenderStats)]
         L.rt_render_device.argtypes = [C.c_void_p, C.POINTER(abi.CameraDesc),
@@ -127,16 +129,18 @@ class Scene:
         return i
 
     def nodes(self):
-        """The BVH nodes as an (n_nodes, 16) float32 array (refs are the bit patterns of [:, 12:14])."""
-        out = np.zeros((self.info().n_nodes, 16), np.float32)
+        """The nodes of the 4-wide BVH as an (n_nodes, 32) float32 array (child k's box: [:, 6k:6k+6] =
+        centre, half extent; the references and the child count are the bit patterns of [:, 24:29])."""
+        out = np.zeros((self.info().n_nodes, 32), np.float32)
         check(lib().rt_scene_read_nodes(self.handle, out.ctypes.data, out.nbytes))
         return out
 
-    def trace(self, rays, tmin=0.001, tmax=np.inf):
+    def trace(self, rays, tmin=0.001, tmax=np.inf, sched=False):
+        """Closest hits of a ray batch; sched=True: through the render kernel's own traversal."""
         rays = np.ascontiguousarray(rays, abi.RAY_DT)
         hits = np.zeros(len(rays), abi.HIT_DT)
-        check(lib().rt_trace_batch(self.handle, rays.ctypes.data, len(rays), tmin, tmax,
-                                   hits.ctypes.data))
+        fn = lib().rt_trace_batch_sched if sched else lib().rt_trace_batch
+        check(fn(self.handle, rays.ctypes.data, len(rays), tmin, tmax, hits.ctypes.data))
         return hits
 
     def render(self, cam, sample_count, sample_begin=0, seed=0, counters=False, accum=None,

@@ -206,18 +206,17 @@ struct Scratch { // frees what the build allocated, whichever way it ends
 
 namespace rtl {
 
-// boxes: n x {lo[3], hi[3]} (host); types: n x RT_PRIM_* (host).  On success *d_nodes holds
-// (n - 1) x 64 bytes of device memory owned by the caller, leaf_order[slot] is the
-// primitive of each leaf slot and *inner_levels the height of the tree.
-hipError_t build_lbvh(const float *boxes, const int *types, int n, float **d_nodes_out, int *leaf_order,
+// boxes: n x {lo[3], hi[3]} (host); types: n x RT_PRIM_* (host).  On success nodes_out (host,
+// (n - 1) x 64 bytes) holds the binary tree, leaf_order[slot] is the primitive of each leaf
+// slot and *inner_levels the height of the tree.
+hipError_t build_lbvh(const float *boxes, const int *types, int n, float *nodes_out, int *leaf_order,
                       int *inner_levels) {
 #define RT_TRY(call)                                                                                        \
     do {                                                                                                    \
         hipError_t e_ = (call);                                                                             \
         if (e_ != hipSuccess) return e_;                                                                    \
     } while (0)
-    *d_nodes_out = nullptr;
-    if (n < 2) return hipErrorInvalidValue;
+    if (n < 2 || !nodes_out) return hipErrorInvalidValue;
     // bounds of the box centres (host: one pass over data that is already here)
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int i = 0; i < n; i++)
@@ -248,14 +247,8 @@ hipError_t build_lbvh(const float *boxes, const int *types, int n, float **d_nod
     RT_TRY(sc.alloc(&d_parent_leaf, (size_t)n));
     RT_TRY(sc.alloc(&d_height, (size_t)n));
     RT_TRY(sc.alloc(&d_arrivals, (size_t)n));
-    float *d_nodes = nullptr;
-    RT_TRY(hipMalloc((void **)&d_nodes, (size_t)(n - 1) * 4 * sizeof(f4)));
-    struct NodeGuard {
-        float *p;
-        ~NodeGuard() {
-            if (p) (void)hipFree(p);
-        }
-    } guard{d_nodes};
+    f4 *d_nodes = nullptr;
+    RT_TRY(sc.alloc(&d_nodes, (size_t)(n - 1) * 4));
 
     RT_TRY(hipMemcpy(d_boxes, boxes, (size_t)n * sizeof(DBox), hipMemcpyHostToDevice));
     RT_TRY(hipMemcpy(d_types, types, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
@@ -274,12 +267,11 @@ hipError_t build_lbvh(const float *boxes, const int *types, int n, float **d_nod
     hipLaunchKernelGGL(fit_boxes, dim3(grid), dim3(256), 0, 0, d_boxes, d_vals_sorted, n, d_left, d_right,
                        d_parent_inner, d_parent_leaf, d_arrivals, d_inner, d_height);
     hipLaunchKernelGGL(emit_nodes, dim3(grid), dim3(256), 0, 0, d_boxes, d_vals_sorted, d_types, n, d_left, d_right,
-                       d_inner, reinterpret_cast<f4 *>(d_nodes));
+                       d_inner, d_nodes);
     RT_TRY(hipGetLastError());
     RT_TRY(hipMemcpy(leaf_order, d_vals_sorted, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
     RT_TRY(hipMemcpy(inner_levels, d_height, sizeof(int), hipMemcpyDeviceToHost)); // node 0 is the root
-    guard.p = nullptr;
-    *d_nodes_out = d_nodes;
+    RT_TRY(hipMemcpy(nodes_out, d_nodes, (size_t)(n - 1) * 4 * sizeof(f4), hipMemcpyDeviceToHost));
     return hipSuccess;
 #undef RT_TRY
 }

@@ -81,6 +81,26 @@ struct Ray {
     float tm;
 };
 
+// Pointers for data every lane of a wave reads at the same address (the primitive list of a
+// scene that is scanned, the wrapper ops of its chains): in device code they point into the
+// constant address space, so that the compiler fetches through the scalar cache into SGPRs
+// (s_load) and branches on the values with scalar branches.  Read-only data only.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RT_UNIFORM_AS __attribute__((address_space(4)))
+#else
+#define RT_UNIFORM_AS
+#endif
+typedef const RT_UNIFORM_AS f4 *uf4_ptr;
+typedef const RT_UNIFORM_AS i4 *ui4_ptr;
+typedef const RT_UNIFORM_AS int *uint_ptr;
+
+// perlin.h:55-56 as the kernels read it: the 256 gradient vectors padded to 16 bytes (one
+// ds_read_b128 / global_load_dwordx4 each) and perm_x.
+struct DevPerlin {
+    f4 randvec[256];
+    int perm_x[256];
+};
+
 // ------------------------------------------------------------------------------------------
 // Scene as the kernels see it.  All pointers are device pointers (the kernels
 // may substitute LDS copies of the first five through a SceneView).
@@ -93,14 +113,17 @@ struct Ray {
 //   material's texture; a solid colour is inlined into rec_f and texture = -1)
 // rec_f: per slot {r g b param}: lambertian / light with a solid texture: the colour;
 //   metal: albedo + fuzz; dielectric: (1,1,1) + refraction index
-// nodes: BVH2 with the two child boxes stored in the parent, 64 bytes:
-//   {c0.x c0.y c0.z h0.x} {h0.y h0.z c1.x c1.y} {c1.z h1.x h1.y h1.z} {ref0 ref1 - -}
-//   (c = centre, h = half extent of a child box)
+// nodes: 4-wide BVH, the child boxes stored in the parent, 128 bytes (layout: trav_inner);
 //   ref >= 0: inner node index; ref < 0: leaf, ~ref = slot*2 + type
 // textures: only the textures reachable from a non-solid material texture (re-indexed)
-// xf   : 3 x 16 bytes per wrapper op {type p0 p1 p2} {sa ca sb cb} {sg cg - -}
+// xf   : RT_XF_F4 x 16 bytes per wrapper op: {type p0 p1 p2} {sa ca sb cb}, then the two
+//   rotation matrices of rotate_xyz row by row, world -> object (hittable.h:299-307) and object ->
+//   world (hittable.h:285-293): {cw0 cw1 cw2 cw3} {cw4 cw5 cw6 cw7} {cw8 ccw0 ccw1 ccw2}
+//   {ccw3 ccw4 ccw5 ccw6} {ccw7 ccw8 - -}.  The entries are the parenthesised products of sines
+//   and cosines the reference evaluates per call, computed once in the same fp32 order.
 enum { TRAV_LINEAR = 0, TRAV_BVH = 1 };
 
+#define RT_XF_F4 7
 #define RT_KIND_PRIM(k) ((k)&1)
 #define RT_KIND_MAT(k) (((k) >> 2) & 3)
 #define RT_KIND_TEX(k) (((k) >> 4) & 3)
@@ -113,7 +136,7 @@ struct DevScene {
     const rt_texture *textures;
     const f4 *xf;
     const int *chain_first; // chain c covers ops [chain_first[c], chain_first[c+1])
-    const rt_perlin *perlins;
+    const DevPerlin *perlins;
     const rt_image *images;
     const uint8_t *texels;
     int n_slots;
@@ -124,7 +147,11 @@ struct DevScene {
     int n_chains;
     int n_xf_ops;
     int lds_records; // LDS staging also covers rec_i / rec_f / textures (else only slots + nodes)
+    int n_perlins;
+    int lds_perlins; // ... and the Perlin tables
     int n_top;       // scenes that stay in HBM: nodes [0, n_top) are also kept in LDS (the top of the tree)
+    int ref_bits;    // low bits of a stack entry that hold a child reference (16 with 16-bit stacks)
+    int stack_cap;   // entries a traversal stack needs (RT_STACK_CAP of the tree's inner levels)
 };
 
 // The five hot arrays, wherever they currently live (HBM or this workgroup's LDS).
@@ -134,6 +161,7 @@ struct SceneView {
     const i4 *rec_i;
     const f4 *rec_f;
     const rt_texture *textures;
+    const DevPerlin *perlins;
     const f4 *top; // LDS copy of nodes [0, n_top) when the scene itself stays in HBM
     int n_top;
 };
@@ -144,6 +172,7 @@ RT_HD SceneView global_view(const DevScene &sc) {
     v.rec_i = sc.rec_i;
     v.rec_f = sc.rec_f;
     v.textures = sc.textures;
+    v.perlins = sc.perlins;
     v.top = nullptr;
     v.n_top = 0;
     return v;
@@ -292,36 +321,66 @@ RT_HD f3 rot_y_cw(f4 a, f3 v) { // hittable.h:169-173
     float vz = a.z * v.x + a.w * v.z;
     return mk(vx, v.y, vz);
 }
-RT_HD f3 rot_xyz_ccw(f4 a, f4 b, f3 v) { // hittable.h:284-295   b = {sg cg - -}
-    float sa = a.x, ca = a.y, sb = a.z, cb = a.w, sg = b.x, cg = b.y;
-    float vx = cb * cg * v.x + (sa * sb * cg - sg * ca) * v.y + (sb * ca * cg + sa * sg) * v.z;
-    float vy = cb * sg * v.x + (ca * cg + sa * sb * sg) * v.y + (-sa * cg + sg * sb * ca) * v.z;
-    float vz = -sb * v.x + sa * cb * v.y + ca * cb * v.z;
+// rotate_xyz with the matrix rows precomputed (rot_matrix_* below evaluate the entries exactly as
+// hittable.h:285-293 / 299-307 write them; a row is applied as m0*x + m1*y + m2*z, left to right).
+struct Mat3 {
+    float m[9];
+};
+RT_HD f3 mat_apply(const Mat3 &r, f3 v) {
+    float vx = r.m[0] * v.x + r.m[1] * v.y + r.m[2] * v.z;
+    float vy = r.m[3] * v.x + r.m[4] * v.y + r.m[5] * v.z;
+    float vz = r.m[6] * v.x + r.m[7] * v.y + r.m[8] * v.z;
     return mk(vx, vy, vz);
 }
-RT_HD f3 rot_xyz_cw(f4 a, f4 b, f3 v) { // hittable.h:298-309
-    float sa = a.x, ca = a.y, sb = a.z, cb = a.w, sg = b.x, cg = b.y;
-    float vx = cb * cg * v.x + sg * cb * v.y - sb * v.z;
-    float vy = (sa * sb * cg - sg * ca) * v.x + (sa * sb * sg + ca * cg) * v.y + sa * cb * v.z;
-    float vz = (sb * ca * cg + sa * sg) * v.x + (sb * sg * ca - sa * cg) * v.y + ca * cb * v.z;
-    return mk(vx, vy, vz);
+RT_HD Mat3 rot_matrix_ccw(float sa, float ca, float sb, float cb, float sg, float cg) { // hittable.h:284-295
+    Mat3 r;
+    r.m[0] = cb * cg, r.m[1] = sa * sb * cg - sg * ca, r.m[2] = sb * ca * cg + sa * sg;
+    r.m[3] = cb * sg, r.m[4] = ca * cg + sa * sb * sg, r.m[5] = -sa * cg + sg * sb * ca;
+    r.m[6] = -sb, r.m[7] = sa * cb, r.m[8] = ca * cb;
+    return r;
+}
+RT_HD Mat3 rot_matrix_cw(float sa, float ca, float sb, float cb, float sg, float cg) { // hittable.h:298-309
+    Mat3 r;
+    r.m[0] = cb * cg, r.m[1] = sg * cb, r.m[2] = -sb;
+    r.m[3] = sa * sb * cg - sg * ca, r.m[4] = sa * sb * sg + ca * cg, r.m[5] = sa * cb;
+    r.m[6] = sb * ca * cg + sa * sg, r.m[7] = sb * sg * ca - sa * cg, r.m[8] = ca * cb;
+    return r;
+}
+// the two matrices of one packed wrapper op (q = its RT_XF_F4 words)
+template <class P4> RT_HD Mat3 xf_matrix_cw(P4 q) {
+    f4 a = q[2], b = q[3], c = q[4];
+    Mat3 r;
+    r.m[0] = a.x, r.m[1] = a.y, r.m[2] = a.z, r.m[3] = a.w, r.m[4] = b.x, r.m[5] = b.y, r.m[6] = b.z, r.m[7] = b.w,
+    r.m[8] = c.x;
+    return r;
+}
+template <class P4> RT_HD Mat3 xf_matrix_ccw(P4 q) {
+    f4 c = q[4], d = q[5], e = q[6];
+    Mat3 r;
+    r.m[0] = c.y, r.m[1] = c.z, r.m[2] = c.w, r.m[3] = d.x, r.m[4] = d.y, r.m[5] = d.z, r.m[6] = d.w, r.m[7] = e.x,
+    r.m[8] = e.y;
+    return r;
 }
 
-// world ray -> object ray: outermost wrapper first.
-RT_HD void chain_ray_to_object(const DevScene &sc, int chain, f3 &o, f3 &d) {
-    int first = sc.chain_first[chain], last = sc.chain_first[chain + 1];
+// world ray -> object ray: outermost wrapper first.  P4 / PI: plain pointers (per-lane chain)
+// or uniform pointers (the whole wave applies the same chain).
+template <class P4, class PI> RT_HD void chain_ray_to_object_p(P4 xf, PI chain_first, int chain, f3 &o, f3 &d) {
+    int first = chain_first[chain], last = chain_first[chain + 1];
     for (int k = last - 1; k >= first; k--) {
-        f4 op = sc.xf[3 * k], a = sc.xf[3 * k + 1], b = sc.xf[3 * k + 2];
+        P4 q = xf + (size_t)k * RT_XF_F4;
+        f4 op = q[0];
         int type = __builtin_bit_cast(int, op.x);
         f3 p = mk(op.y, op.z, op.w);
         if (type == RT_XF_TRANSLATE) {
             o = o - p;
         } else if (type == RT_XF_ROTATE_Y) {
+            f4 a = q[1];
             o = rot_y_cw(a, o);
             d = rot_y_cw(a, d);
         } else if (type == RT_XF_ROTATE_XYZ) {
-            o = rot_xyz_cw(a, b, o);
-            d = rot_xyz_cw(a, b, d);
+            Mat3 r = xf_matrix_cw(q);
+            o = mat_apply(r, o);
+            d = mat_apply(r, d);
         } else {
             o = o / p;
             d = d / p;
@@ -329,25 +388,34 @@ RT_HD void chain_ray_to_object(const DevScene &sc, int chain, f3 &o, f3 &d) {
     }
 }
 // object-space hit point and normal -> world: innermost wrapper first.
-RT_HD void chain_hit_to_world(const DevScene &sc, int chain, f3 &p, f3 &n) {
-    int first = sc.chain_first[chain], last = sc.chain_first[chain + 1];
+template <class P4, class PI> RT_HD void chain_hit_to_world_p(P4 xf, PI chain_first, int chain, f3 &p, f3 &n) {
+    int first = chain_first[chain], last = chain_first[chain + 1];
     for (int k = first; k < last; k++) {
-        f4 op = sc.xf[3 * k], a = sc.xf[3 * k + 1], b = sc.xf[3 * k + 2];
+        P4 q = xf + (size_t)k * RT_XF_F4;
+        f4 op = q[0];
         int type = __builtin_bit_cast(int, op.x);
         f3 s = mk(op.y, op.z, op.w);
         if (type == RT_XF_TRANSLATE) {
             p = p + s;
         } else if (type == RT_XF_ROTATE_Y) {
+            f4 a = q[1];
             p = rot_y_ccw(a, p);
             n = rot_y_ccw(a, n);
         } else if (type == RT_XF_ROTATE_XYZ) {
-            p = rot_xyz_ccw(a, b, p);
-            n = rot_xyz_ccw(a, b, n);
+            Mat3 r = xf_matrix_ccw(q);
+            p = mat_apply(r, p);
+            n = mat_apply(r, n);
         } else {
             p = p * s;
             n = unit(n / s);
         }
     }
+}
+RT_HD void chain_ray_to_object(const DevScene &sc, int chain, f3 &o, f3 &d) {
+    chain_ray_to_object_p(sc.xf, sc.chain_first, chain, o, d);
+}
+RT_HD void chain_hit_to_world(const DevScene &sc, int chain, f3 &p, f3 &n) {
+    chain_hit_to_world_p(sc.xf, sc.chain_first, chain, p, n);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -358,7 +426,9 @@ struct TraceHit {
 };
 
 // hittable_list::hit (hittable_list.h:29-43): scan in test order with a shrinking
-// interval.
+// interval.  Every lane of the wave walks the same list: the primitives, their records and
+// the wrapper ops are read through uniform pointers (scalar loads on the device), whatever
+// copy of the scene `v` names.
 template <bool COUNT>
 RT_HD TraceHit trace_linear(const DevScene &sc, const SceneView &v, const Ray &r, float tmin, float tmax,
                             Cnt<COUNT> &cn) {
@@ -367,21 +437,26 @@ RT_HD TraceHit trace_linear(const DevScene &sc, const SceneView &v, const Ray &r
     best.slot = -1;
     int cur_chain = -1;
     f3 o = r.o, d = r.d;
+    float dd = len2(d);
     const int stride = sc.slot_f4;
+    const uf4_ptr u_slots = (uf4_ptr)sc.slots;
+    const ui4_ptr u_rec = (ui4_ptr)sc.rec_i;
     for (int s = 0; s < sc.n_slots; s++) {
-        i4 m = v.rec_i[s];
+        const i4 m = u_rec[s];
         if (m.z != cur_chain) {
             cur_chain = m.z;
             o = r.o;
             d = r.d;
-            if (RT_FEAT_CHAIN && cur_chain >= 0) chain_ray_to_object(sc, cur_chain, o, d);
+            if (RT_FEAT_CHAIN && cur_chain >= 0)
+                chain_ray_to_object_p((uf4_ptr)sc.xf, (uint_ptr)sc.chain_first, cur_chain, o, d);
+            dd = len2(d);
         }
-        const f4 *g = v.slots + (size_t)s * stride;
+        const uf4_ptr g = u_slots + (size_t)s * stride;
         float t;
         bool h;
         if (!RT_FEAT_QUAD || RT_KIND_PRIM(m.x) == RT_PRIM_SPHERE) {
             RT_COUNT(sph);
-            h = sphere_test(g[0], g[1], o, d, len2(d), r.tm, tmin, best.t, t);
+            h = sphere_test(g[0], g[1], o, d, dd, r.tm, tmin, best.t, t);
             if constexpr (COUNT) cn.sphh += h ? 1 : 0;
         } else {
             RT_COUNT(quad);
@@ -450,8 +525,8 @@ RT_HD bool box_hit(f3 c, f3 h, const BoxRay &b, float tmin, float tmax, float &t
     float nx = __builtin_fmaf(-h.x, ix, mx), fx = __builtin_fmaf(h.x, ix, mx);
     float ny = __builtin_fmaf(-h.y, iy, my), fy = __builtin_fmaf(h.y, iy, my);
     float nz = __builtin_fmaf(-h.z, iz, mz), fz = __builtin_fmaf(h.z, iz, mz);
-    tn = fmaxf(fmaxf(nx, ny), fmaxf(nz, tmin));
-    float tf = fminf(fminf(fx, fy), fminf(fz, tmax));
+    tn = fmaxf(fmaxf(fmaxf(nx, ny), nz), tmin); // (v_max3_f32 + v_max_f32)
+    float tf = fminf(fminf(fminf(fx, fy), fz), tmax);
     // exit parameter widened by the absolute slack (2e) and a relative one (2^-19 tf) for the
     // rounding of the fma results themselves; when the test is close, |tn| ~ |tf|.  One FMA:
     // for tf < 0 the relative part narrows instead, by less than 2^-19 * tmin where it could
@@ -460,9 +535,23 @@ RT_HD bool box_hit(f3 c, f3 h, const BoxRay &b, float tmin, float tmax, float &t
     return tn <= tf_wide;
 }
 
-#ifndef RT_STACK_DEPTH
-#define RT_STACK_DEPTH 32
-#endif
+// Deepest tree the builders produce (inner levels of the binary tree the wide tree is
+// collapsed from; the wide tree is never deeper).
+#define RT_MAX_TREE_LEVELS 30
+// Entries a traversal stack needs for a wide tree of `levels` inner levels: a node leaves at
+// most three children behind, and the step writes four entries before it takes one back.
+#define RT_STACK_CAP(levels) (3 * (levels) + 2)
+
+// Traversal stack of one lane: a column of a [entry][lane] array, so that the lanes of a
+// wave touch consecutive banks / addresses.  Entries [0, lds_cap) live in LDS; scenes whose
+// tree is too deep for that keep the entries beyond in a second column in global memory (only
+// rays that have that many subtrees pending ever get there).
+template <typename T> struct TravStack {
+    T *lds;
+    int *spill;   // null: the LDS column holds the whole stack
+    int stride;   // elements between consecutive entries (both columns)
+    int lds_end;  // lds_cap * stride
+};
 
 // BVH traversal as a resumable state machine, so that a wave can interleave the
 // traversal steps of its 64 rays with shading (rt_kernels.hip) instead of waiting
@@ -474,7 +563,7 @@ struct Trav {
     float best_t;
     int best_slot;
     int ref;
-    int sp; // stack offset in elements (already multiplied by the stride)
+    int sp; // entries on the stack, times the stride
     bool best_is_quad;
     float dd; // |d|^2 of the world-space ray
 };
@@ -487,46 +576,89 @@ RT_HD void trav_begin(Trav &tv, const Ray &r, float tmax) {
     tv.ref = 0; // root
     tv.sp = 0;
 }
-template <typename StackT> RT_HD void trav_pop(Trav &tv, const StackT *stack, int stack_stride) {
+
+// A stack entry is a sort key: the child's entry parameter in the high bits (a positive float
+// orders like its bit pattern), its reference in the low ref_bits bits.  16-bit stacks keep
+// only the low half (ref_bits = 16 there); 32-bit stacks keep the key and cut the reference
+// out when it is popped.
+template <typename T> RT_HD int stack_entry_ref(T e, int ref_bits) {
+    if (sizeof(T) == 2) return (int)e;
+    const int sh = 32 - ref_bits;
+    return ((int)e << sh) >> sh;
+}
+template <typename T, bool SPILL> RT_HD void trav_pop(Trav &tv, const TravStack<T> &st, int ref_bits) {
     if (tv.sp == 0) {
         tv.ref = RT_TRAV_DONE;
-    } else {
-        tv.sp -= stack_stride;
-        tv.ref = (int)stack[tv.sp];
+        return;
     }
-}
-// One inner node (requires tv.ref >= 0): tests both children, descends into the
-// nearer one that is hit and pushes the other.
-// TOP: nodes [0, n_top) are read from `top` (the workgroup's LDS) instead of `nodes` (HBM).
-template <bool COUNT, typename StackT, bool TOP = false>
-RT_HD void trav_inner(Trav &tv, const f4 *nodes, float tmin, StackT *stack, int stack_stride, Cnt<COUNT> &cn,
-                      const f4 *top = nullptr, int n_top = 0) {
-    f4 n0, n1, n2, n3;
-    if (TOP && tv.ref < n_top) { // two explicit paths: LDS reads and global loads, no flat addressing
-        const f4 *n = top + (size_t)tv.ref * 4;
-        n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
-    } else {
-        const f4 *n = nodes + (size_t)tv.ref * 4;
-        n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
-    }
-    if constexpr (COUNT) cn.box += 2;
-    float e0, e1;
-    bool h0 = box_hit(mk(n0.x, n0.y, n0.z), mk(n0.w, n1.x, n1.y), tv.br, tmin, tv.best_t, e0);
-    bool h1 = box_hit(mk(n1.z, n1.w, n2.x), mk(n2.y, n2.z, n2.w), tv.br, tmin, tv.best_t, e1);
-    int r0 = __builtin_bit_cast(int, n3.x), r1 = __builtin_bit_cast(int, n3.y);
-    // selects instead of a three-way branch: the nearer hit child is visited next, the other
-    // hit child (if any) is pushed; only "no child hit" needs the stack read
-    bool second_first = h1 && (!h0 || e1 < e0);
-    int nearr = second_first ? r1 : r0;
-    int farr = second_first ? r0 : r1;
-    if (h0 && h1) {
-        stack[tv.sp] = (StackT)farr;
-        tv.sp += stack_stride;
-    }
-    if (h0 || h1)
-        tv.ref = nearr;
+    tv.sp -= st.stride;
+    if (!SPILL || tv.sp < st.lds_end)
+        tv.ref = stack_entry_ref<T>(st.lds[tv.sp], ref_bits);
     else
-        trav_pop(tv, stack, stack_stride);
+        tv.ref = stack_entry_ref<int>(st.spill[tv.sp - st.lds_end], ref_bits);
+}
+
+RT_HD unsigned umin_(unsigned a, unsigned b) { return a < b ? a : b; }
+RT_HD unsigned umax_(unsigned a, unsigned b) { return a > b ? a : b; }
+
+// One inner node (requires tv.ref >= 0) of the 4-wide tree: tests the four child boxes, puts
+// the children that are hit on the stack, farthest first, and takes the nearest back.
+// Node, 8 x 16 bytes: the boxes as centre c and half extent h
+//   {c0.xyz h0.x} {h0.yz c1.xy} {c1.z h1.xyz} {c2.xyz h2.x} {h2.yz c3.xy} {c3.z h3.xyz}
+//   {ref0 ref1 ref2 ref3} {number of children, - - -}
+// An unused child has an inverted box (never hit).  The four keys (0 for a child that is
+// missed) are sorted in descending order with integer min / max and all four are written
+// above the stack's top: the farthest child lands lowest, the missed ones above the new top
+// where they do not count.  No branch depends on how many children were hit.
+// TOP: nodes [0, n_top) are read from `top` (the workgroup's LDS) instead of `nodes` (HBM).
+template <bool COUNT, typename T, bool TOP, bool SPILL>
+RT_HD void trav_inner(Trav &tv, const f4 *nodes, float tmin, const TravStack<T> &st, int ref_bits, Cnt<COUNT> &cn,
+                      const f4 *top = nullptr, int n_top = 0) {
+    f4 q0, q1, q2, q3, q4, q5, q6;
+    if (TOP && tv.ref < n_top) { // two explicit paths: LDS reads and global loads, no flat addressing
+        const f4 *n = top + (size_t)tv.ref * 8;
+        q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3], q4 = n[4], q5 = n[5], q6 = n[6];
+        if constexpr (COUNT) cn.box += __builtin_bit_cast(int, n[7].x);
+    } else {
+        const f4 *n = nodes + (size_t)tv.ref * 8;
+        q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3], q4 = n[4], q5 = n[5], q6 = n[6];
+        if constexpr (COUNT) cn.box += __builtin_bit_cast(int, n[7].x);
+    }
+    float e0, e1, e2, e3;
+    const bool h0 = box_hit(mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), tv.br, tmin, tv.best_t, e0);
+    const bool h1 = box_hit(mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w), tv.br, tmin, tv.best_t, e1);
+    const bool h2 = box_hit(mk(q3.x, q3.y, q3.z), mk(q3.w, q4.x, q4.y), tv.br, tmin, tv.best_t, e2);
+    const bool h3 = box_hit(mk(q4.z, q4.w, q5.x), mk(q5.y, q5.z, q5.w), tv.br, tmin, tv.best_t, e3);
+    const unsigned lo = ref_bits >= 32 ? ~0u : (1u << ref_bits) - 1u;
+    // (e & ~lo) | (ref & lo): one v_bfi_b32 each
+    const unsigned k0 = h0 ? ((__builtin_bit_cast(unsigned, e0) & ~lo) | (__builtin_bit_cast(unsigned, q6.x) & lo)) : 0u;
+    const unsigned k1 = h1 ? ((__builtin_bit_cast(unsigned, e1) & ~lo) | (__builtin_bit_cast(unsigned, q6.y) & lo)) : 0u;
+    const unsigned k2 = h2 ? ((__builtin_bit_cast(unsigned, e2) & ~lo) | (__builtin_bit_cast(unsigned, q6.z) & lo)) : 0u;
+    const unsigned k3 = h3 ? ((__builtin_bit_cast(unsigned, e3) & ~lo) | (__builtin_bit_cast(unsigned, q6.w) & lo)) : 0u;
+    const unsigned hi01 = umax_(k0, k1), lo01 = umin_(k0, k1), hi23 = umax_(k2, k3), lo23 = umin_(k2, k3);
+    const unsigned a0 = umax_(hi01, hi23), a3 = umin_(lo01, lo23);
+    const unsigned m1 = umin_(hi01, hi23), m2 = umax_(lo01, lo23);
+    const unsigned a1 = umax_(m1, m2), a2 = umin_(m1, m2);
+    const int n_hit = (int)h0 + (int)h1 + (int)h2 + (int)h3;
+    const int sp = tv.sp, sd = st.stride;
+    if (!SPILL || sp + 3 * sd < st.lds_end) {
+        st.lds[sp] = (T)a0;
+        st.lds[sp + sd] = (T)a1;
+        st.lds[sp + 2 * sd] = (T)a2;
+        st.lds[sp + 3 * sd] = (T)a3;
+    } else {
+        const unsigned a[4] = {a0, a1, a2, a3};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int p = sp + i * sd;
+            if (p < st.lds_end)
+                st.lds[p] = (T)a[i];
+            else
+                st.spill[p - st.lds_end] = (int)a[i];
+        }
+    }
+    tv.sp = sp + n_hit * sd;
+    trav_pop<T, SPILL>(tv, st, ref_bits);
 }
 // Exact test of one leaf against the current best (ties included).
 template <bool COUNT>
@@ -574,18 +706,18 @@ RT_HD void trav_test_leaf(Trav &tv, int leaf_ref, const DevScene &sc, const Scen
     }
 }
 
-// Whole traversal of one ray (parity entry point, host logic check).
-template <bool COUNT, typename StackT>
+// Whole traversal of one ray.
+template <bool COUNT, typename T, bool SPILL = false>
 RT_HD TraceHit trace_bvh(const DevScene &sc, const SceneView &v, const Ray &r, float tmin, float tmax,
-                         StackT *stack, int stack_stride, Cnt<COUNT> &cn) {
+                         const TravStack<T> &st, Cnt<COUNT> &cn) {
     Trav tv;
     trav_begin(tv, r, tmax);
     while (tv.ref != RT_TRAV_DONE) {
         if (tv.ref >= 0) {
-            trav_inner<COUNT, StackT>(tv, v.nodes, tmin, stack, stack_stride, cn);
+            trav_inner<COUNT, T, false, SPILL>(tv, v.nodes, tmin, st, sc.ref_bits, cn);
         } else {
             trav_test_leaf<COUNT>(tv, tv.ref, sc, v, r, tmin, cn);
-            trav_pop(tv, stack, stack_stride);
+            trav_pop<T, SPILL>(tv, st, sc.ref_bits);
         }
     }
     TraceHit best;
@@ -648,7 +780,7 @@ RT_HD Surf surface_at(const DevScene &sc, const SceneView &vw, const Ray &r, Tra
 
 // ------------------------------------------------------------------------------------------
 // Textures (texture.h:16-95, perlin.h:17-95)
-RT_HD float perlin_noise(const rt_perlin &pn, f3 p) {
+RT_HD float perlin_noise(const DevPerlin &pn, f3 p) {
     float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
     float u = p.x - fx, v = p.y - fy, w = p.z - fz;
     int i = int(fx), j = int(fy), k = int(fz);
@@ -667,14 +799,14 @@ RT_HD float perlin_noise(const rt_perlin &pn, f3 p) {
 #pragma unroll
             for (int dk = 0; dk < 2; dk++) {
                 int idx = (di ? pi1 : pi0) ^ (dj ? pj1 : pj0) ^ (dk ? pk1 : pk0);
-                f3 c = mk(pn.randvec[idx][0], pn.randvec[idx][1], pn.randvec[idx][2]);
+                f3 c = xyz(pn.randvec[idx]);
                 f3 wv = mk(u - di, v - dj, w - dk);
                 accum += (di * uu + (1 - di) * (1 - uu)) * (dj * vv + (1 - dj) * (1 - vv)) *
                          (dk * ww + (1 - dk) * (1 - ww)) * dot(c, wv);
             }
     return accum;
 }
-RT_HD float perlin_turb(const rt_perlin &pn, f3 p, int depth) {
+RT_HD float perlin_turb(const DevPerlin &pn, f3 p, int depth) {
     float accum = 0.0f;
     float weight = 1.0f;
     for (int i = 0; i < depth; i++) {
@@ -701,7 +833,7 @@ RT_HD f3 texture_value(const DevScene &sc, const SceneView &vw, int tex, const S
     if (t.type == RT_TEX_SOLID) return mk(t.color[0], t.color[1], t.color[2]);
     if (RT_FEAT_NOISE && t.type == RT_TEX_NOISE) { // texture.h:85-90
         RT_COUNT(noise);
-        float ph = t.scale * s.p.z + 10.0f * perlin_turb(sc.perlins[t.perlin], s.p, 7);
+        float ph = t.scale * s.p.z + 10.0f * perlin_turb(vw.perlins[t.perlin], s.p, 7);
         return mk(0.5f, 0.5f, 0.5f) * (1.0f + sinf(ph));
     }
     if (RT_FEAT_IMAGE && t.type == RT_TEX_IMAGE) { // texture.h:60-74, rtw_stb_image.h:69-94
@@ -854,16 +986,16 @@ RT_HD bool path_after_trace(const DevScene &sc, const SceneView &vw, const DevCa
 
 // One whole segment of ray_color: trace, then miss / emit / scatter.  Returns true
 // while the path continues; when it returns false ps.L holds the path's radiance.
-template <int TRAV, bool COUNT, typename StackT>
-RT_HD bool path_step(const DevScene &sc, const SceneView &vw, const DevCamera &cam, PathState &ps, StackT *stack,
-                     int stack_stride, unsigned &n_rays, Cnt<COUNT> &cn) {
+template <int TRAV, bool COUNT, typename T, bool SPILL>
+RT_HD bool path_step(const DevScene &sc, const SceneView &vw, const DevCamera &cam, PathState &ps,
+                     const TravStack<T> &st, unsigned &n_rays, Cnt<COUNT> &cn) {
     if (ps.depth <= 0) return false; // camera.h:141
     n_rays++;
     TraceHit h;
     if constexpr (TRAV == TRAV_LINEAR)
         h = trace_linear<COUNT>(sc, vw, ps.ray, 0.001f, RT_INF, cn);
     else
-        h = trace_bvh<COUNT, StackT>(sc, vw, ps.ray, 0.001f, RT_INF, stack, stack_stride, cn);
+        h = trace_bvh<COUNT, T, SPILL>(sc, vw, ps.ray, 0.001f, RT_INF, st, cn);
     return path_after_trace<COUNT>(sc, vw, cam, ps, h, cn);
 }
 

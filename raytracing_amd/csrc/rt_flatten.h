@@ -26,9 +26,9 @@ using rtc::mk;
 const int kLinearMaxPrims = 32;       // at most this many primitives: scan, no tree
 const int kMaxLdsBytes = 160 * 1024;  // LDS per CU on gfx950
 const int kParallelBuildMinPrims = 65536; // scenes from this size on: subtrees built by several threads
-const int kTreeTopMin = 2560;         // trees of at least this many 64-byte nodes never fit LDS whole
-const int kTreeTopMax = 2048;         // nodes moved to the front for the LDS copy of the tree's top
-const int kMaxInnerDepth = RT_STACK_DEPTH - 2;
+const int kTreeTopMin = 1280;         // trees of at least this many 128-byte nodes never fit LDS whole
+const int kTreeTopMax = 1024;         // nodes moved to the front for the LDS copy of the tree's top
+const int kMaxInnerDepth = RT_MAX_TREE_LEVELS - 1; // of the binary tree (the root is at depth 0)
 
 // ---------------------------------------------------------------------------------------
 // wrapper ops on the host (same formulas as rt_core.h uses on the device)
@@ -36,6 +36,7 @@ struct HostOp {
     int type;
     f3 p;
     f4 a, b; // {sa ca sb cb} {sg cg 0 0}
+    rtc::Mat3 cw, ccw; // rotate_xyz: world -> object and object -> world
 };
 
 HostOp make_op(const rt_xform_op &op) {
@@ -58,6 +59,8 @@ HostOp make_op(const rt_xform_op &op) {
         h.b.x = sinf(gr);
         h.b.y = cosf(gr);
     }
+    h.cw = rtc::rot_matrix_cw(h.a.x, h.a.y, h.a.z, h.a.w, h.b.x, h.b.y);
+    h.ccw = rtc::rot_matrix_ccw(h.a.x, h.a.y, h.a.z, h.a.w, h.b.x, h.b.y);
     return h;
 }
 
@@ -65,7 +68,7 @@ f3 op_point(const HostOp &h, f3 p) {
     switch (h.type) {
     case RT_XF_TRANSLATE: return p + h.p;
     case RT_XF_ROTATE_Y: return rtc::rot_y_ccw(h.a, p);
-    case RT_XF_ROTATE_XYZ: return rtc::rot_xyz_ccw(h.a, h.b, p);
+    case RT_XF_ROTATE_XYZ: return rtc::mat_apply(h.ccw, p);
     default: return p * h.p;
     }
 }
@@ -73,7 +76,7 @@ f3 op_vector(const HostOp &h, f3 v) {
     switch (h.type) {
     case RT_XF_TRANSLATE: return v;
     case RT_XF_ROTATE_Y: return rtc::rot_y_ccw(h.a, v);
-    case RT_XF_ROTATE_XYZ: return rtc::rot_xyz_ccw(h.a, h.b, v);
+    case RT_XF_ROTATE_XYZ: return rtc::mat_apply(h.ccw, v);
     default: return v * h.p;
     }
 }
@@ -145,20 +148,103 @@ inline void center_half(const Box3 &b, float *c, float *h) {
     }
 }
 
-// Moves the most visited part of a tree to the front of the node array, so that a kernel
+// ---------------------------------------------------------------------------------------
+// The 4-wide tree the kernels walk (rt_core.h trav_inner: 128-byte nodes holding the boxes of up
+// to four children) is collapsed from the binary tree the builders make (64-byte nodes:
+// {c0.xyz h0.x} {h0.yz c1.xy} {c1.z h1.xyz} {ref0 ref1 - -}).
+inline float half_area(const float *h) { return h[0] * h[1] + h[1] * h[2] + h[2] * h[0]; }
+
+struct Wide {
+    std::vector<f4> nodes; // 8 per node
+    int n_nodes = 0;
+    int levels = 0;        // inner levels (a tree that is one node has 1)
+};
+
+// Every wide node starts from a binary node's two children and keeps replacing the inner child
+// with the largest box by that child's own two children until it has four (or only leaves).
+inline Wide collapse_to_wide(const std::vector<f4> &bin) {
+    Wide w;
+    const int n2 = (int)(bin.size() / 4);
+    if (n2 == 0) return w;
+    w.nodes.reserve((size_t)(n2 / 2 + 1) * 8);
+    struct Child {
+        float box[6]; // centre, half extent
+        int ref;      // reference in the binary tree
+    };
+    auto children_of = [&](int node, Child out[2]) {
+        const float *q = reinterpret_cast<const float *>(&bin[(size_t)node * 4]);
+        for (int k = 0; k < 2; k++) {
+            memcpy(out[k].box, q + 6 * k, 6 * sizeof(float));
+            out[k].ref = __builtin_bit_cast(int, q[12 + k]);
+        }
+    };
+    struct Item {
+        int bin_node, wide_node, level;
+    };
+    std::vector<Item> todo;
+    auto new_node = [&]() {
+        w.nodes.resize(w.nodes.size() + 8, f4{0.0f, 0.0f, 0.0f, 0.0f});
+        return w.n_nodes++;
+    };
+    todo.push_back({0, new_node(), 1});
+    while (!todo.empty()) {
+        const Item it = todo.back();
+        todo.pop_back();
+        w.levels = std::max(w.levels, it.level);
+        Child c[4];
+        int n = 2;
+        children_of(it.bin_node, c);
+        while (n < 4) {
+            int pick = -1;
+            float best = -1.0f;
+            for (int k = 0; k < n; k++)
+                if (c[k].ref >= 0 && half_area(c[k].box + 3) > best) {
+                    best = half_area(c[k].box + 3);
+                    pick = k;
+                }
+            if (pick < 0) break;
+            Child two[2];
+            children_of(c[pick].ref, two);
+            c[pick] = two[0]; // the left child keeps the place: the order of the leaves is the binary tree's
+            for (int k = n; k > pick + 1; k--) c[k] = c[k - 1];
+            c[pick + 1] = two[1];
+            n++;
+        }
+        int refs[4] = {0, 0, 0, 0};
+        float boxes[24];
+        for (int k = 0; k < 4; k++) {
+            if (k < n) {
+                memcpy(boxes + 6 * k, c[k].box, 6 * sizeof(float));
+                if (c[k].ref >= 0) {
+                    refs[k] = new_node();
+                    todo.push_back({c[k].ref, refs[k], it.level + 1});
+                } else {
+                    refs[k] = c[k].ref;
+                }
+            } else { // unused: a box no ray enters
+                for (int a = 0; a < 3; a++) {
+                    boxes[6 * k + a] = 0.0f;
+                    boxes[6 * k + 3 + a] = -1e30f;
+                }
+            }
+        }
+        float *q = reinterpret_cast<float *>(&w.nodes[(size_t)it.wide_node * 8]);
+        memcpy(q, boxes, sizeof(boxes));
+        for (int k = 0; k < 4; k++) q[24 + k] = __builtin_bit_cast(float, refs[k]);
+        q[28] = __builtin_bit_cast(float, n);
+    }
+    return w;
+}
+
+// Moves the most visited part of a wide tree to the front of the node array, so that a kernel
 // can keep a prefix of it in LDS while the rest stays in HBM.  Nodes are picked greedily by
 // the surface area of their box (the chance that a random ray visits them), starting at the
 // root; every prefix of the new order is a connected top of the tree.  The remaining nodes
 // keep their relative order.  Returns the number of nodes picked (at most max_top).
 inline int reorder_tree_top(std::vector<f4> &nodes, int max_top) {
-    const int n = (int)(nodes.size() / 4);
+    const int n = (int)(nodes.size() / 8);
     if (n <= 1 || max_top <= 0) return n <= 1 ? n : 0;
-    auto child_ref = [&](int node, int k) { return __builtin_bit_cast(int, k == 0 ? nodes[(size_t)node * 4 + 3].x : nodes[(size_t)node * 4 + 3].y); };
-    auto child_area = [&](int node, int k) {
-        const f4 *q = &nodes[(size_t)node * 4];
-        float hx = k == 0 ? q[0].w : q[2].y, hy = k == 0 ? q[1].x : q[2].z, hz = k == 0 ? q[1].y : q[2].w;
-        return hx * hy + hy * hz + hz * hx;
-    };
+    auto words = [&](int node) { return reinterpret_cast<float *>(&nodes[(size_t)node * 8]); };
     std::vector<int> picked;
     std::vector<std::pair<float, int>> heap; // (area, node)
     picked.reserve(max_top);
@@ -168,10 +254,12 @@ inline int reorder_tree_top(std::vector<f4> &nodes, int max_top) {
         int node = heap.back().second;
         heap.pop_back();
         picked.push_back(node);
-        for (int k = 0; k < 2; k++) {
-            int r = child_ref(node, k);
+        const float *q = words(node);
+        const int nc = __builtin_bit_cast(int, q[28]);
+        for (int k = 0; k < nc; k++) {
+            int r = __builtin_bit_cast(int, q[24 + k]);
             if (r >= 0) {
-                heap.push_back({child_area(node, k), r});
+                heap.push_back({half_area(q + 6 * k + 3), r});
                 std::push_heap(heap.begin(), heap.end());
             }
         }
@@ -183,24 +271,25 @@ inline int reorder_tree_top(std::vector<f4> &nodes, int max_top) {
         if (new_index[i] < 0) new_index[i] = next++;
     std::vector<f4> out(nodes.size());
     for (int i = 0; i < n; i++) {
-        f4 *q = &out[(size_t)new_index[i] * 4];
-        memcpy(q, &nodes[(size_t)i * 4], 4 * sizeof(f4));
-        int r0 = __builtin_bit_cast(int, q[3].x), r1 = __builtin_bit_cast(int, q[3].y);
-        if (r0 >= 0) q[3].x = __builtin_bit_cast(float, new_index[r0]);
-        if (r1 >= 0) q[3].y = __builtin_bit_cast(float, new_index[r1]);
+        float *q = reinterpret_cast<float *>(&out[(size_t)new_index[i] * 8]);
+        memcpy(q, words(i), 8 * sizeof(f4));
+        const int nc = __builtin_bit_cast(int, q[28]);
+        for (int k = 0; k < nc; k++) {
+            int r = __builtin_bit_cast(int, q[24 + k]);
+            if (r >= 0) q[24 + k] = __builtin_bit_cast(float, new_index[r]);
+        }
     }
     nodes.swap(out);
     return (int)picked.size();
 }
 
 // ---------------------------------------------------------------------------------------
-// Binned-SAH BVH2 builder.  Leaves hold one primitive; a parent stores the boxes
-// of both children (one 64-byte fetch tests both).
+// Binned-SAH builder of the binary tree.  Leaves hold one primitive; a parent stores the
+// boxes of both children.
 struct BvhOut {
-    std::vector<f4> nodes;       // 4 per node (empty if an external builder keeps them elsewhere)
+    std::vector<f4> nodes;       // 4 per binary node
     std::vector<int> leaf_order; // slot -> input primitive index
     int max_inner_depth = 0;
-    int n_nodes = 0;             // set by external builders; the host builder's is nodes.size() / 4
 };
 
 class BvhBuilder {
@@ -436,8 +525,9 @@ struct HostScene {
     std::vector<i4> rec_i;       // per slot {kind, texture, chain, prim id}   (rt_core.h)
     std::vector<f4> rec_f;       // per slot {r g b param}
     std::vector<rt_texture> textures; // textures reachable from non-solid material textures
-    std::vector<f4> nodes;       // 4 per BVH node (empty: linear scan)
-    std::vector<f4> xf;          // 3 per wrapper op, packed chain by chain
+    std::vector<f4> nodes;       // 8 per node of the 4-wide tree (empty: linear scan)
+    std::vector<f4> xf;          // RT_XF_F4 per wrapper op, packed chain by chain
+    std::vector<rtc::DevPerlin> perlins;
     std::vector<int> chain_first; // n_chains + 1
     int slot_f4 = 2;
     int n_prims = 0, n_spheres = 0, n_quads = 0;
@@ -445,13 +535,14 @@ struct HostScene {
     int n_top = 0; // nodes [0, n_top) are the most visited ones (reorder_tree_top); 0: order as built
     bool linear = true;
     bool any_chain = false; // some primitive sits inside instance wrappers
-    bool external_nodes = false; // the nodes were built (and are kept) by the external builder
+    bool external_nodes = false; // the binary tree came from the external (device) builder
+    int n_bin_nodes = 0;         // nodes of the binary tree the wide one was collapsed from
 };
 
 // flags: RT_SCENE_FORCE_* (rt_amd.h).  The descriptor must already be validated.
 // An external builder (the device-side one) gets the padded world-space boxes and the
-// primitive types and fills leaf_order, max_inner_depth and n_nodes; returning false falls
-// back to the host builder.
+// primitive types and fills the binary nodes, leaf_order and max_inner_depth; returning false
+// falls back to the host builder.
 using ExternalBuilder = std::function<bool(const std::vector<Box3> &, const std::vector<int> &, BvhOut &)>;
 
 inline int flatten_scene(const rt_scene_desc *d, uint32_t flags, HostScene &out, std::string &err,
@@ -550,26 +641,27 @@ inline int flatten_scene(const rt_scene_desc *d, uint32_t flags, HostScene &out,
         bool built = false;
         if (external) {
             built = external(boxes, types, bo) && (int)bo.leaf_order.size() == n &&
-                    bo.max_inner_depth <= kMaxInnerDepth;
+                    (int)bo.nodes.size() == 4 * (n - 1) && bo.max_inner_depth <= kMaxInnerDepth;
             if (!built) bo = BvhOut();
         }
         if (!built) {
             BvhBuilder builder(boxes, types);
             bo = builder.run();
-            bo.n_nodes = (int)(bo.nodes.size() / 4);
         }
         out.external_nodes = built;
-        nodes = std::move(bo.nodes);
+        out.n_bin_nodes = (int)(bo.nodes.size() / 4);
+        Wide wide = collapse_to_wide(bo.nodes);
+        nodes = std::move(wide.nodes);
         // trees too large for LDS: their top is cached there (kTreeTopMin nodes is more than a CU's LDS holds)
-        out.n_top = (!built && bo.n_nodes >= kTreeTopMin) ? reorder_tree_top(nodes, kTreeTopMax) : 0;
+        out.n_top = wide.n_nodes >= kTreeTopMin ? reorder_tree_top(nodes, kTreeTopMax) : 0;
         slots.resize((size_t)n * slot_f4);
         for (int sl = 0; sl < n; sl++) {
             int pi = bo.leaf_order[sl];
             memcpy(&slots[(size_t)sl * slot_f4], &geom[(size_t)pi * slot_f4], sizeof(f4) * slot_f4);
             meta[sl] = i4{types[pi], d->prims[pi].material, d->prims[pi].xform, pi};
         }
-        out.n_nodes = bo.n_nodes;
-        out.bvh_depth = bo.max_inner_depth + 1;
+        out.n_nodes = wide.n_nodes;
+        out.bvh_depth = wide.levels;
     }
 
     // per-slot shading records: the material (and a solid colour) inlined, so that the
@@ -620,23 +712,35 @@ inline int flatten_scene(const rt_scene_desc *d, uint32_t flags, HostScene &out,
         }
     }
 
-    // wrapper ops / chains (only the linear scan applies them at run time)
-    std::vector<f4> xf((size_t)d->n_xform_ops * 3);
-    for (int i = 0; i < d->n_xform_ops; i++) {
-        xf[3 * i] = f4{__builtin_bit_cast(float, ops[i].type), ops[i].p.x, ops[i].p.y, ops[i].p.z};
-        xf[3 * i + 1] = ops[i].a;
-        xf[3 * i + 2] = ops[i].b;
-    }
-    // chains are re-packed so that chain c covers ops [chain_first[c], chain_first[c+1])
+    // wrapper ops, re-packed chain by chain so that chain c covers ops [chain_first[c], chain_first[c+1])
     std::vector<f4> &xf_packed = out.xf;
     std::vector<int> &chain_first = out.chain_first;
     chain_first.assign(d->n_chains + 1, 0);
     for (int c = 0; c < d->n_chains; c++) {
-        chain_first[c] = (int)(xf_packed.size() / 3);
-        for (int k = 0; k < d->chains[c].n_ops; k++)
-            for (int w = 0; w < 3; w++) xf_packed.push_back(xf[3 * (d->chains[c].first_op + k) + w]);
+        chain_first[c] = (int)(xf_packed.size() / RT_XF_F4);
+        for (int k = 0; k < d->chains[c].n_ops; k++) {
+            const HostOp &h = ops[d->chains[c].first_op + k];
+            const float *cw = h.cw.m, *cc = h.ccw.m;
+            xf_packed.push_back(f4{__builtin_bit_cast(float, h.type), h.p.x, h.p.y, h.p.z});
+            xf_packed.push_back(h.a);
+            xf_packed.push_back(f4{cw[0], cw[1], cw[2], cw[3]});
+            xf_packed.push_back(f4{cw[4], cw[5], cw[6], cw[7]});
+            xf_packed.push_back(f4{cw[8], cc[0], cc[1], cc[2]});
+            xf_packed.push_back(f4{cc[3], cc[4], cc[5], cc[6]});
+            xf_packed.push_back(f4{cc[7], cc[8], 0.0f, 0.0f});
+        }
     }
-    chain_first[d->n_chains] = (int)(xf_packed.size() / 3);
+    chain_first[d->n_chains] = (int)(xf_packed.size() / RT_XF_F4);
+
+    // Perlin tables in the kernels' layout
+    out.perlins.resize((size_t)d->n_perlins);
+    for (int i = 0; i < d->n_perlins; i++) {
+        for (int k = 0; k < 256; k++) {
+            const float *rv = d->perlins[i].randvec[k];
+            out.perlins[i].randvec[k] = f4{rv[0], rv[1], rv[2], 0.0f};
+            out.perlins[i].perm_x[k] = d->perlins[i].perm_x[k];
+        }
+    }
 
     return RT_OK;
 }

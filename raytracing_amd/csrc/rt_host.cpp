@@ -98,6 +98,9 @@ struct rt_scene {
     void *strip_tmp = nullptr;
     size_t strip_tmp_bytes = 0;
     unsigned strip_cap = 0;
+    // scenes read from HBM with a tree too deep for the LDS part of the stacks: the rest of every
+    // lane's stack, one buffer per record set and one for rt_render_device_static
+    int *stack_spill[3] = {nullptr, nullptr, nullptr};
     unsigned long long *d_words = nullptr; // [0] pool counter, [1] ray counter
     rtc::Counters *d_counters = nullptr;
     int n_cu = 256;
@@ -207,7 +210,7 @@ int validate(const rt_scene_desc *d) {
 // Bytes of LDS the staged arrays take: slots, nodes, both per-slot records, textures
 // (the latter padded to 16 bytes).  Must match the kernels' staging order.
 size_t scene_lds_bytes(const rtc::DevScene &dv) {
-    size_t words = (size_t)dv.n_slots * dv.slot_f4 + (size_t)dv.n_nodes * 4 + (size_t)dv.n_slots * 2;
+    size_t words = (size_t)dv.n_slots * dv.slot_f4 + (size_t)dv.n_nodes * 8 + (size_t)dv.n_slots * 2;
     size_t tex = ((size_t)dv.n_textures * sizeof(rt_texture) + 15) / 16;
     return (words + tex) * sizeof(f4);
 }
@@ -224,8 +227,8 @@ LaunchGeom choose_geom(rt_scene *s, uint32_t flags) {
     LaunchGeom lg;
     rtc::DevScene &dv = s->dev;
     const bool bvh = dv.traversal == rtc::TRAV_BVH;
-    const int levels = s->info.bvh_depth + 1;
-    const size_t geom_bytes = ((size_t)dv.n_slots * dv.slot_f4 + (size_t)dv.n_nodes * 4) * sizeof(f4);
+    const int cap = bvh ? RT_STACK_CAP(s->info.bvh_depth) : 0; // stack entries a ray can need
+    const size_t geom_bytes = ((size_t)dv.n_slots * dv.slot_f4 + (size_t)dv.n_nodes * 8) * sizeof(f4);
     const size_t all_bytes = scene_lds_bytes(dv);
     const int block = std::max(64, std::min(1024, env_int("RT_AMD_BLOCK", 1024) / 64 * 64));
     const int threads_per_cu = rtl::mega_waves_per_simd() * 256;
@@ -234,6 +237,8 @@ LaunchGeom choose_geom(rt_scene *s, uint32_t flags) {
     lg.block = block;
     lg.lds_scene = false;
     lg.lds_records = 0;
+    lg.stack_cap = cap;
+    lg.stack_lds_entries = cap;
     int bpc = bpc_target;
     // the render kernels' camera-ray rings (one per wave) come after the stacks if there is room
     const size_t ring_bytes = env_int("RT_AMD_RING", 1) != 0
@@ -244,7 +249,7 @@ LaunchGeom choose_geom(rt_scene *s, uint32_t flags) {
     if (!(flags & RT_SCENE_FORCE_GLOBAL) && short_ok) {
         for (bpc = bpc_target; bpc >= 1 && !lg.lds_scene; bpc--) {
             size_t budget = (size_t)kMaxLdsBytes / bpc;
-            size_t stack = bvh ? (size_t)levels * block * sizeof(short) : 0;
+            size_t stack = (size_t)cap * block * sizeof(short);
             if (all_bytes + stack <= budget) {
                 lg.lds_scene = true;
                 lg.lds_records = 1;
@@ -260,13 +265,28 @@ LaunchGeom choose_geom(rt_scene *s, uint32_t flags) {
             }
             if (lg.lds_scene) {
                 lg.ring = ring_bytes && used + ring_bytes <= budget;
+                // the Perlin tables come along if everything else fits (they follow the records)
+                const size_t perlin_bytes = (size_t)dv.n_perlins * sizeof(rtc::DevPerlin);
+                if (lg.lds_records && perlin_bytes > 0 && env_int("RT_AMD_LDS_PERLIN", 1) != 0 &&
+                    used + perlin_bytes + (lg.ring ? ring_bytes : 0) <= budget) {
+                    lg.lds_perlins = 1;
+                    used += perlin_bytes;
+                }
                 break;
             }
         }
     }
     dv.n_top = 0;
-    if (!lg.lds_scene) { // geometry stays in HBM; LDS holds the 32-bit stacks, the rings and the top of the tree
-        size_t stack = bvh ? (size_t)levels * block * sizeof(int) : 0;
+    dv.ref_bits = 16;
+    if (!lg.lds_scene) {
+        // Geometry stays in HBM.  LDS holds the top entries of the 32-bit stacks (the rest of a
+        // deep tree's stack, which few rays ever reach, spills to global memory), the rings and
+        // the most visited nodes of the tree.
+        int bits = 1;
+        while ((1ll << bits) < std::max<long long>(dv.n_nodes, 2ll * dv.n_slots)) bits++;
+        dv.ref_bits = std::max(16, std::min(32, bits + 1));
+        lg.stack_lds_entries = bvh ? std::max(4, std::min(cap, env_int("RT_AMD_LDS_STACK", 24))) : 0;
+        size_t stack = (size_t)lg.stack_lds_entries * block * sizeof(int);
         bpc = std::max(1, std::min(bpc_target, (int)(kMaxLdsBytes / std::max<size_t>(stack + ring_bytes, 1))));
         size_t budget = (size_t)kMaxLdsBytes / bpc;
         lg.ring = ring_bytes && stack + ring_bytes <= budget;
@@ -274,11 +294,12 @@ LaunchGeom choose_geom(rt_scene *s, uint32_t flags) {
         if (bvh && s->tree_top > 0 && env_int("RT_AMD_TREE_TOP", 1) != 0) {
             size_t taken = stack + (lg.ring ? ring_bytes : 0);
             size_t room = budget > taken ? budget - taken : 0;
-            dv.n_top = (int)std::min<size_t>((size_t)s->tree_top, room / (4 * sizeof(f4)));
+            dv.n_top = (int)std::min<size_t>((size_t)s->tree_top, room / (8 * sizeof(f4)));
             dv.n_top = std::min(dv.n_top, std::max(0, env_int("RT_AMD_TREE_TOP_NODES", dv.n_top)));
-            used += (size_t)dv.n_top * 4 * sizeof(f4);
+            used += (size_t)dv.n_top * 8 * sizeof(f4);
         }
     }
+    dv.stack_cap = cap;
     used = (used + 15) / 16 * 16;
     lg.ring_f4 = (int)(used / sizeof(f4));
     lg.lds_bytes = (int)(used + (lg.ring ? ring_bytes : 0));
@@ -367,7 +388,6 @@ static int impl_rt_scene_create(const rt_scene_desc *d, int device, uint32_t fla
     if (rc != RT_OK) return rc;
 
     rtf::HostScene hs;
-    float *d_built_nodes = nullptr; // RT_SCENE_BUILD_DEVICE: the tree stays where it was built
     const auto t_build0 = std::chrono::steady_clock::now();
     {
         std::string err;
@@ -376,26 +396,20 @@ static int impl_rt_scene_create(const rt_scene_desc *d, int device, uint32_t fla
             device_builder = [&](const std::vector<rtf::Box3> &boxes, const std::vector<int> &types, rtf::BvhOut &bo) {
                 static_assert(sizeof(rtf::Box3) == 6 * sizeof(float), "Box3 is six floats");
                 const int np = (int)boxes.size();
+                if (np < 2) return false;
                 bo.leaf_order.resize((size_t)np);
+                bo.nodes.resize((size_t)(np - 1) * 4);
                 int levels = 0;
                 hipError_t e = rtl::build_lbvh(reinterpret_cast<const float *>(boxes.data()), types.data(), np,
-                                               &d_built_nodes, bo.leaf_order.data(), &levels);
+                                               reinterpret_cast<float *>(bo.nodes.data()), bo.leaf_order.data(), &levels);
                 if (e != hipSuccess) return false; // host builder takes over
                 bo.max_inner_depth = levels - 1;
-                bo.n_nodes = np - 1;
                 return true;
             };
         if (env_int("RT_AMD_FORCE_BVH", 0)) flags |= RT_SCENE_FORCE_BVH; // experiments: a tree for small scenes too
         if (env_int("RT_AMD_FORCE_GLOBAL", 0)) flags |= RT_SCENE_FORCE_GLOBAL; // ... no LDS copy of the scene
         rc = rtf::flatten_scene(d, flags, hs, err, device_builder);
-        if (rc != RT_OK) {
-            if (d_built_nodes) hipFree(d_built_nodes);
-            return fail(rc, "%s", err.c_str());
-        }
-        if (d_built_nodes && !hs.external_nodes) { // built, then rejected (too deep): host tree in use
-            hipFree(d_built_nodes);
-            d_built_nodes = nullptr;
-        }
+        if (rc != RT_OK) return fail(rc, "%s", err.c_str());
     }
     const double build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build0).count();
     const int n = hs.n_prims;
@@ -422,24 +436,18 @@ static int impl_rt_scene_create(const rt_scene_desc *d, int device, uint32_t fla
     s->info.built_on_device = hs.external_nodes ? 1 : 0;
 
     const std::vector<rt_texture> &texs = hs.textures;
-    std::vector<rt_perlin> perl(d->perlins, d->perlins + d->n_perlins);
     std::vector<rt_image> imgs(d->images, d->images + d->n_images);
     std::vector<uint8_t> texels(d->texels, d->texels + d->n_texel_bytes);
 
     rtc::DevScene &dv = s->dev;
-    if (d_built_nodes) { // the scene owns the device-built tree from here on
-        dv.nodes = reinterpret_cast<const f4 *>(d_built_nodes);
-        s->allocs.push_back(d_built_nodes);
-        s->info.device_bytes += (size_t)hs.n_nodes * 4 * sizeof(f4);
-    }
     rc = upload(s, slots, &dv.slots);
     if (rc == RT_OK) rc = upload(s, rec_i, &dv.rec_i);
     if (rc == RT_OK) rc = upload(s, rec_f, &dv.rec_f);
-    if (rc == RT_OK && !d_built_nodes) rc = upload(s, nodes, &dv.nodes);
+    if (rc == RT_OK) rc = upload(s, nodes, &dv.nodes);
     if (rc == RT_OK) rc = upload(s, xf_packed, &dv.xf);
     if (rc == RT_OK) rc = upload(s, chain_first, &dv.chain_first);
     if (rc == RT_OK) rc = upload(s, texs, &dv.textures);
-    if (rc == RT_OK) rc = upload(s, perl, &dv.perlins);
+    if (rc == RT_OK) rc = upload(s, hs.perlins, &dv.perlins);
     if (rc == RT_OK) rc = upload(s, imgs, &dv.images);
     if (rc == RT_OK) rc = upload(s, texels, &dv.texels);
     std::vector<unsigned long long> words(8, 0ull); // 0 / 2: pool counters, 1: rays, 4 / 5: batch counters
@@ -465,7 +473,9 @@ static int impl_rt_scene_create(const rt_scene_desc *d, int device, uint32_t fla
     dv.slot_f4 = slot_f4;
     dv.traversal = linear ? rtc::TRAV_LINEAR : rtc::TRAV_BVH;
     dv.n_chains = d->n_chains;
-    dv.n_xf_ops = (int)(xf_packed.size() / 3);
+    dv.n_xf_ops = (int)(xf_packed.size() / RT_XF_F4);
+    dv.n_perlins = (int)hs.perlins.size();
+    dv.lds_perlins = 0; // set per launch from the launch geometry
     dv.lds_records = 0; // set per launch from the launch geometry
 
     int n_cu = 0;
@@ -481,6 +491,19 @@ static int impl_rt_scene_create(const rt_scene_desc *d, int device, uint32_t fla
     }
 
     s->geom = choose_geom(s, flags);
+    if (s->geom.stack_cap > s->geom.stack_lds_entries) {
+        const size_t bytes = (size_t)(s->geom.stack_cap - s->geom.stack_lds_entries) * s->geom.grid * s->geom.block * sizeof(int);
+        for (int k = 0; k < 3; k++) {
+            void *p = nullptr;
+            if (hipMalloc(&p, bytes) != hipSuccess) {
+                rt_scene_destroy(s);
+                return fail(RT_ERR_HIP, "cannot allocate the traversal stacks' overflow area (%zu bytes)", bytes);
+            }
+            s->allocs.push_back(p);
+            s->stack_spill[k] = (int *)p;
+            s->info.device_bytes += bytes;
+        }
+    }
     if (env_int("RT_AMD_DEBUG", 0))
         fprintf(stderr, "librt_amd: render geometry grid %d block %d lds %d (scene %d records %d), resident blocks/CU %d\n",
                 s->geom.grid, s->geom.block, s->geom.lds_bytes, (int)s->geom.lds_scene, s->geom.lds_records,
@@ -492,7 +515,7 @@ static int impl_rt_scene_create(const rt_scene_desc *d, int device, uint32_t fla
 
 int rt_scene_read_nodes(rt_scene *s, void *out, uint64_t bytes) {
     if (!s || !out) return fail(RT_ERR_ARG, "null argument");
-    if (bytes != (uint64_t)s->info.n_nodes * 4 * sizeof(f4)) return fail(RT_ERR_ARG, "expected n_nodes * 64 bytes");
+    if (bytes != (uint64_t)s->info.n_nodes * 8 * sizeof(f4)) return fail(RT_ERR_ARG, "expected n_nodes * 128 bytes");
     int rc = set_device(s->device);
     if (rc != RT_OK) return rc;
     if (bytes) RT_HIP(hipMemcpy(out, s->dev.nodes, bytes, hipMemcpyDeviceToHost));
@@ -581,6 +604,7 @@ RenderParams base_params(int W, int H, int n_pixels, const rt_render_opts *opts,
     rp.n_units = rp.n_strips * (unsigned)sc_n;
     rp.pixel_major = tn.unit_order;
     rp.ring_f4 = lg.ring_f4;
+    rp.stack_lds_entries = lg.stack_lds_entries;
     rp.scheduler = tn.scheduler;
     rp.min_ready = tn.min_ready;
     rp.leaf_min = tn.leaf_min;
@@ -673,6 +697,7 @@ static int impl_rt_render_device(rt_scene *s, const rt_camera_desc *cam, const r
     const int scheduler = tn.scheduler;
     rtc::DevScene dev = s->dev;
     dev.lds_records = lg.lds_records;
+    dev.lds_perlins = lg.lds_perlins;
     unsigned wf_slots = 0;
     int wf_rounds = 0;
     if (wavefront) {
@@ -773,6 +798,7 @@ static int impl_rt_render_device(rt_scene *s, const rt_camera_desc *cam, const r
             if (s->strip_valid[b] == rp.n_strips) rp.strip_order = s->strip_order[b];
         }
         rp.stage = s->stage[b];
+        rp.stack_spill = s->stack_spill[b];
         rp.next_chunk = reinterpret_cast<unsigned *>(s->d_words + 2 * b); // words 0 / 2: pool counters, 1: rays
         rp.counters = count ? s->d_counters : nullptr;
         if (pipelined && s->spill[b] && s->dev.traversal == rtc::TRAV_BVH && scheduler == 1) {
@@ -913,10 +939,12 @@ static int impl_rt_render_device_static(rt_scene *s, const rt_camera_desc *cam, 
     const Tunables tn = read_tunables(lg.lds_scene);
     rtc::DevScene dev = s->dev;
     dev.lds_records = lg.lds_records;
+    dev.lds_perlins = lg.lds_perlins;
     for (int done = 0; done < opts->sample_count; done += chunk) {
         const int sc_n = std::min(chunk, opts->sample_count - done);
         RenderParams rp = base_params(W, H, n_pixels, opts, done, sc_n, lg, tn);
         rp.stage = stage;
+        rp.stack_spill = s->stack_spill[2]; // (allocated with the scene, not here)
         rp.next_chunk = reinterpret_cast<unsigned *>(words);
         // the block keeps the last call's contents: the counters must start at zero
         RT_HIP(hipMemsetAsync(words, 0, 2 * sizeof(unsigned long long), stream));
@@ -958,13 +986,45 @@ int rt_trace_batch_device(rt_scene *s, const rt_ray *d_rays, int64_t n, float tm
     if (n == 0) return RT_OK;
     int rc = set_device(s->device);
     if (rc != RT_OK) return rc;
-    if (s->dev.traversal == rtc::TRAV_BVH && s->info.bvh_depth + 1 > RT_STACK_DEPTH)
-        return fail(RT_ERR_UNSUPPORTED, "tree deeper than the traversal stack");
-    RT_HIP(rtl::launch_trace(s->dev, d_rays, n, tmin, tmax, d_hits, (hipStream_t)stream));
+    rtc::DevScene dev = s->dev;
+    dev.ref_bits = 32; // whole keys on 32-bit stacks would do; the parity kernel keeps plain references
+    RT_HIP(rtl::launch_trace(dev, d_rays, n, tmin, tmax, d_hits, (hipStream_t)stream));
     return RT_OK;
 }
 
-int rt_trace_batch(rt_scene *s, const rt_ray *rays, int64_t n, float tmin, float tmax, rt_hit *hits) {
+// Scenes that are scanned have one closest-hit routine (trace_linear) in every kernel: the
+// scheduled variant only exists for trees.
+int rt_trace_batch_sched_device(rt_scene *s, const rt_ray *d_rays, int64_t n, float tmin, float tmax, rt_hit *d_hits,
+                                void *stream_v) {
+    if (!s || n < 0 || (n > 0 && (!d_rays || !d_hits))) return fail(RT_ERR_ARG, "bad argument");
+    if (n == 0) return RT_OK;
+    if (s->dev.traversal != rtc::TRAV_BVH) return rt_trace_batch_device(s, d_rays, n, tmin, tmax, d_hits, stream_v);
+    int rc = set_device(s->device);
+    if (rc != RT_OK) return rc;
+    hipStream_t stream = (hipStream_t)stream_v;
+    // record set 0's stack overflow area and a spare counter word: order behind whatever used them
+    for (int k = 0; k < 2; k++)
+        if (s->ev_free_valid[k]) RT_HIP(hipStreamWaitEvent(stream, s->ev_free[k], 0));
+    const LaunchGeom lg = s->geom;
+    const Tunables tn = read_tunables(lg.lds_scene);
+    rt_render_opts o;
+    memset(&o, 0, sizeof(o));
+    RenderParams rp = base_params(1, 1, 1, &o, 0, 1, lg, tn);
+    rp.stack_spill = s->stack_spill[0];
+    rp.next_chunk = reinterpret_cast<unsigned *>(s->d_words + 6);
+    rtc::DevScene dev = s->dev;
+    dev.lds_records = lg.lds_records;
+    dev.lds_perlins = lg.lds_perlins;
+    RT_HIP(hipMemsetAsync(s->d_words + 6, 0, sizeof(unsigned long long), stream));
+    RT_HIP(rtl::launch_trace_sched(dev, rp, lg, d_rays, n, tmin, tmax, d_hits, stream));
+    if (!s->ev_free[0]) RT_HIP(hipEventCreateWithFlags(&s->ev_free[0], hipEventDisableTiming));
+    RT_HIP(hipEventRecord(s->ev_free[0], stream));
+    s->ev_free_valid[0] = true;
+    return RT_OK;
+}
+
+namespace {
+int trace_batch_host(rt_scene *s, const rt_ray *rays, int64_t n, float tmin, float tmax, rt_hit *hits, bool sched) {
     if (!s || n < 0 || (n > 0 && (!rays || !hits))) return fail(RT_ERR_ARG, "bad argument");
     if (n == 0) return RT_OK;
     int rc = set_device(s->device);
@@ -975,7 +1035,8 @@ int rt_trace_batch(rt_scene *s, const rt_ray *rays, int64_t n, float tmin, float
     hipError_t e = hipMalloc((void **)&d_hits, sizeof(rt_hit) * n);
     if (e == hipSuccess) e = hipMemcpy(d_rays, rays, sizeof(rt_ray) * n, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        rc = rt_trace_batch_device(s, d_rays, n, tmin, tmax, d_hits, nullptr);
+        rc = sched ? rt_trace_batch_sched_device(s, d_rays, n, tmin, tmax, d_hits, nullptr)
+                   : rt_trace_batch_device(s, d_rays, n, tmin, tmax, d_hits, nullptr);
         if (rc == RT_OK) e = hipDeviceSynchronize();
         if (rc == RT_OK && e == hipSuccess) e = hipMemcpy(hits, d_hits, sizeof(rt_hit) * n, hipMemcpyDeviceToHost);
     }
@@ -984,6 +1045,14 @@ int rt_trace_batch(rt_scene *s, const rt_ray *rays, int64_t n, float tmin, float
     if (rc != RT_OK) return rc;
     if (e != hipSuccess) return fail(RT_ERR_HIP, "trace batch: %s", hipGetErrorString(e));
     return RT_OK;
+}
+} // namespace
+
+int rt_trace_batch(rt_scene *s, const rt_ray *rays, int64_t n, float tmin, float tmax, rt_hit *hits) {
+    return trace_batch_host(s, rays, n, tmin, tmax, hits, false);
+}
+int rt_trace_batch_sched(rt_scene *s, const rt_ray *rays, int64_t n, float tmin, float tmax, rt_hit *hits) {
+    return trace_batch_host(s, rays, n, tmin, tmax, hits, true);
 }
 
 // write_color (color.h:17-32): sqrt gamma, clamp to [0, 0.999], 256 * c truncated.

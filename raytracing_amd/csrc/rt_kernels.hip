@@ -38,6 +38,83 @@ using namespace rtc;
 
 namespace {
 
+// Lane states of the decoupled kernels.
+enum { ST_IDLE = 0, ST_TRAV = 1, ST_READY = 2 };
+
+struct SchedStats { // wave-level schedule statistics (instrumented variants only)
+    unsigned long long t_iters = 0, t_lanes = 0, l_iters = 0, l_lanes = 0;
+    long long c_inner = 0, c_leaf = 0;
+};
+
+// The traversal half of the decoupled scheme, shared by the render kernel and by the batch
+// kernel that puts caller-supplied rays through the same code (trace_sched): runs node steps
+// for the lanes in ST_TRAV, RT_INNER_UNROLL per scheduling decision, until `min_ready` lanes
+// wait for something else (a finished traversal, or — if idle lanes can be given new work,
+// `idle_counts` — nothing at all) or no lane traverses any more.  A leaf does not stop its
+// lane: it is parked in the lane's `pend` and the traversal goes on; parked leaves are tested
+// together once leaf_min lanes hold one, blocked_min lanes have run into a second leaf, or no
+// lane has an inner node left.  Lanes whose traversal ends leave in ST_READY with the closest
+// hit in tv.best_t / tv.best_slot.
+template <bool LDS_SCENE, bool COUNT, typename T, bool SPILL>
+__device__ __forceinline__ void wave_traverse(int &state, Trav &tv, int &pend, const Ray &ray, const DevScene &sc,
+                                              const SceneView &vw, const TravStack<T> &st, float tmin, int min_ready,
+                                              int leaf_min, int blocked_min, bool idle_counts, Cnt<COUNT> &cn,
+                                              SchedStats &ss) {
+    long long c_mark = 0;
+    for (;;) {
+        unsigned long long tmask = __ballot(state == ST_TRAV);
+        if (tmask == 0ull) break;
+        unsigned long long rmask = __ballot(state == ST_READY || (state == ST_IDLE && idle_counts));
+        if (__popcll(rmask) >= min_ready) break;
+        if constexpr (COUNT) {
+            unsigned long long im0 = __ballot(state == ST_TRAV && tv.ref >= 0);
+            if (im0) {
+                ss.t_iters++;
+                ss.t_lanes += __popcll(im0);
+            }
+            c_mark = clock64();
+        }
+        const bool trav = state == ST_TRAV;
+#pragma unroll
+        for (int k = 0; k < RT_INNER_UNROLL; k++) {
+            if (trav && tv.ref >= 0)
+                trav_inner<COUNT, T, !LDS_SCENE, SPILL>(tv, vw.nodes, tmin, st, sc.ref_bits, cn, vw.top, vw.n_top);
+            if (trav && tv.ref < 0 && tv.ref != RT_TRAV_DONE && pend == 0) {
+                pend = tv.ref;
+                trav_pop<T, SPILL>(tv, st, sc.ref_bits);
+            }
+        }
+        if constexpr (COUNT) {
+            const long long now = clock64();
+            ss.c_inner += now - c_mark;
+            c_mark = now;
+        }
+        const bool blocked = trav && tv.ref < 0 && tv.ref != RT_TRAV_DONE; // second leaf, slot taken
+        const bool has_pend = trav && pend != 0;
+        unsigned long long pmask = __ballot(has_pend);
+        if (pmask != 0ull) {
+            unsigned long long imask = __ballot(trav && tv.ref >= 0);
+            unsigned long long bmask = __ballot(blocked);
+            if (__popcll(pmask) >= leaf_min || __popcll(bmask) >= blocked_min || imask == 0ull) {
+                if constexpr (COUNT) {
+                    ss.l_iters++;
+                    ss.l_lanes += __popcll(pmask);
+                }
+                if (has_pend) {
+                    trav_test_leaf<COUNT>(tv, pend, sc, vw, ray, tmin, cn);
+                    pend = 0;
+                    if (blocked) {
+                        pend = tv.ref;
+                        trav_pop<T, SPILL>(tv, st, sc.ref_bits);
+                    }
+                }
+            }
+        }
+        if constexpr (COUNT) ss.c_leaf += clock64() - c_mark;
+        if (trav && tv.ref == RT_TRAV_DONE && pend == 0) state = ST_READY;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // One whole ray per lane per iteration.  Linear scenes: every lane walks the same
 // primitive list, so the traversal itself is divergence-free.
@@ -52,8 +129,8 @@ render_mega(DevScene sc, DevCamera cam, RenderParams rp) {
     if constexpr (LDS_SCENE) free_lds = stage_scene(sc, smem, vw);
     else __syncthreads();
     using StackT = typename std::conditional<LDS_SCENE, short, int>::type;
-    StackT *stack = reinterpret_cast<StackT *>(free_lds) + threadIdx.x;
-    const int stack_stride = blockDim.x;
+    constexpr bool SPILL = !LDS_SCENE;
+    const TravStack<StackT> st = lane_stack<StackT, SPILL>(free_lds, sc, rp.stack_lds_entries, rp.stack_spill);
     // RING: the camera rays of the wave's current unit (see render_mega_bvh)
     f4 *ring = RING ? smem + rp.ring_f4 + (size_t)(threadIdx.x >> 6) * RT_RING_F4_PER_WAVE : nullptr;
 
@@ -140,7 +217,7 @@ render_mega(DevScene sc, DevCamera cam, RenderParams rp) {
                     if constexpr (TRAV == TRAV_LINEAR)
                         h = trace_linear<COUNT>(sc, vw, ps.ray, 0.001f, RT_INF, cn);
                     else
-                        h = trace_bvh<COUNT, StackT>(sc, vw, ps.ray, 0.001f, RT_INF, stack, stack_stride, cn);
+                        h = trace_bvh<COUNT, StackT, SPILL>(sc, vw, ps.ray, 0.001f, RT_INF, st, cn);
                 }
                 long long c1 = clock64();
                 if (go) cont = path_after_trace<COUNT>(sc, vw, cam, ps, h, cn);
@@ -152,7 +229,7 @@ render_mega(DevScene sc, DevCamera cam, RenderParams rp) {
                     w_cycles[4] += __popcll(__ballot(true));
                 }
             } else {
-                cont = path_step<TRAV, COUNT, StackT>(sc, vw, cam, ps, stack, stack_stride, n_rays, cn);
+                cont = path_step<TRAV, COUNT, StackT, SPILL>(sc, vw, cam, ps, st, n_rays, cn);
             }
             if (!cont) {
                 write_record(rp, sample, pixel, ps.L, n_rays);
@@ -190,14 +267,14 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
     if constexpr (LDS_SCENE) free_lds = stage_scene(sc, smem, vw);
     using StackT = typename std::conditional<LDS_SCENE, short, int>::type;
     if constexpr (!LDS_SCENE) { // the scene stays in HBM: the top of the tree comes along
-        stage_to_lds(free_lds, sc.nodes, sc.n_top * 4);
+        stage_to_lds(free_lds, sc.nodes, sc.n_top * 8);
         vw.top = free_lds;
         vw.n_top = sc.n_top;
-        free_lds += (size_t)sc.n_top * 4;
+        free_lds += (size_t)sc.n_top * 8;
         __syncthreads();
     }
-    StackT *stack = reinterpret_cast<StackT *>(free_lds) + threadIdx.x;
-    const int stack_stride = blockDim.x;
+    constexpr bool SPILL = !LDS_SCENE;
+    const TravStack<StackT> st = lane_stack<StackT, SPILL>(free_lds, sc, rp.stack_lds_entries, rp.stack_spill);
     // RING: the camera rays of the wave's current unit, structure of arrays over its 64 paths
     f4 *ring = RING ? smem + rp.ring_f4 + (size_t)(threadIdx.x >> 6) * RT_RING_F4_PER_WAVE : nullptr;
 
@@ -209,7 +286,6 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
     const int regen_min = rp.regen_min;
     int pend = 0; // parked leaf reference (leaf references are negative; 0 = none)
 
-    enum { ST_IDLE = 0, ST_TRAV = 1, ST_READY = 2 };
     WavePool wp;
     pool_init(wp);
     int state = ST_IDLE;
@@ -227,8 +303,9 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
     bool have_batch = false;
     unsigned batch = 0;
     // wave-level schedule statistics (instrumented variant only), kept by lane 0
-    unsigned long long w_t_iters = 0, w_t_lanes = 0, w_l_iters = 0, w_l_lanes = 0, w_s_phases = 0, w_s_lanes = 0;
-    long long c_shade = 0, c_regen = 0, c_inner = 0, c_leaf = 0, c_mark = 0;
+    unsigned long long w_s_phases = 0, w_s_lanes = 0;
+    SchedStats ss;
+    long long c_shade = 0, c_regen = 0, c_mark = 0;
     const long long c_begin = COUNT ? clock64() : 0;
     unsigned long long w_start = 0, w_dry = 0;
     if constexpr (COUNT) w_start = wall_clock64();
@@ -419,59 +496,8 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
             continue;
         }
         // ---- traversal steps until enough lanes wait for shading ------------------------------
-        for (;;) {
-            unsigned long long tmask = __ballot(state == ST_TRAV);
-            if (tmask == 0ull) break;
-            unsigned long long rmask = __ballot(state == ST_READY || (state == ST_IDLE && !pool_dry));
-            if (__popcll(rmask) >= min_ready) break;
-            if constexpr (COUNT) {
-                unsigned long long im0 = __ballot(state == ST_TRAV && tv.ref >= 0);
-                if (im0) {
-                    w_t_iters++;
-                    w_t_lanes += __popcll(im0);
-                }
-            }
-            const bool trav = state == ST_TRAV;
-            RT_TICK();
-            // RT_INNER_UNROLL node steps per scheduling decision: the ballots / thresholds
-            // below cost about as much as a node step, so they are amortised.
-#pragma unroll
-            for (int k = 0; k < RT_INNER_UNROLL; k++) {
-                if (trav && tv.ref >= 0)
-                    trav_inner<COUNT, StackT, !LDS_SCENE>(tv, vw.nodes, 0.001f, stack, stack_stride, cn, vw.top, vw.n_top);
-                // A leaf does not stop the lane: it is parked in the lane's pending slot and the
-                // traversal goes on; parked leaves are tested together once enough lanes hold one.
-                if (trav && tv.ref < 0 && tv.ref != RT_TRAV_DONE && pend == 0) {
-                    pend = tv.ref;
-                    trav_pop(tv, stack, stack_stride);
-                }
-            }
-            RT_TOCK(c_inner);
-            RT_TICK();
-            const bool blocked = trav && tv.ref < 0 && tv.ref != RT_TRAV_DONE; // second leaf, slot taken
-            const bool has_pend = trav && pend != 0;
-            unsigned long long pmask = __ballot(has_pend);
-            if (pmask != 0ull) {
-                unsigned long long imask = __ballot(trav && tv.ref >= 0);
-                unsigned long long bmask = __ballot(blocked);
-                if (__popcll(pmask) >= leaf_min || __popcll(bmask) >= blocked_min || imask == 0ull) {
-                    if constexpr (COUNT) {
-                        w_l_iters++;
-                        w_l_lanes += __popcll(pmask);
-                    }
-                    if (has_pend) {
-                        trav_test_leaf<COUNT>(tv, pend, sc, vw, ps.ray, 0.001f, cn);
-                        pend = 0;
-                        if (blocked) {
-                            pend = tv.ref;
-                            trav_pop(tv, stack, stack_stride);
-                        }
-                    }
-                }
-            }
-            RT_TOCK(c_leaf);
-            if (trav && tv.ref == RT_TRAV_DONE && pend == 0) state = ST_READY;
-        }
+        wave_traverse<LDS_SCENE, COUNT, StackT, SPILL>(state, tv, pend, ps.ray, sc, vw, st, 0.001f, min_ready, leaf_min,
+                                                       blocked_min, !pool_dry, cn, ss);
     }
     };
     run_phase(std::false_type{});
@@ -489,17 +515,17 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
     if constexpr (COUNT) {
         flush_counters<COUNT>(rp.counters, cn);
         if (lane == 0) {
-            atomicAdd(&rp.counters->sched[0], w_t_iters);
-            atomicAdd(&rp.counters->sched[1], w_t_lanes);
-            atomicAdd(&rp.counters->sched[2], w_l_iters);
-            atomicAdd(&rp.counters->sched[3], w_l_lanes);
+            atomicAdd(&rp.counters->sched[0], ss.t_iters);
+            atomicAdd(&rp.counters->sched[1], ss.t_lanes);
+            atomicAdd(&rp.counters->sched[2], ss.l_iters);
+            atomicAdd(&rp.counters->sched[3], ss.l_lanes);
             atomicAdd(&rp.counters->sched[4], w_s_phases);
             atomicAdd(&rp.counters->sched[5], w_s_lanes);
             atomicAdd(&rp.counters->cycles[0], (unsigned long long)(clock64() - c_begin));
             atomicAdd(&rp.counters->cycles[1], (unsigned long long)c_shade);
             atomicAdd(&rp.counters->cycles[2], (unsigned long long)c_regen);
-            atomicAdd(&rp.counters->cycles[3], (unsigned long long)c_inner);
-            atomicAdd(&rp.counters->cycles[4], (unsigned long long)c_leaf);
+            atomicAdd(&rp.counters->cycles[3], (unsigned long long)ss.c_inner);
+            atomicAdd(&rp.counters->cycles[4], (unsigned long long)ss.c_leaf);
             atomicMin(&rp.counters->tail[0], w_start);
             atomicMin(&rp.counters->tail[1], w_dry ? w_dry : ~0ull);
             atomicMax(&rp.counters->tail[2], w_dry);
@@ -560,11 +586,42 @@ __global__ void __launch_bounds__(256) tonemap_u8(const float *accum, long long 
     rgb8[i] = (uint8_t) int(256 * g);
 }
 
+// hit_record of the closest hit (hittable.h:10-26) plus the primitive id.
+__device__ __forceinline__ rt_hit make_hit_record(const DevScene &sc, const SceneView &vw, const Ray &r, TraceHit h) {
+    rt_hit out;
+    out.prim = -1;
+    out.front_face = 0;
+    out.t = 0.0f;
+    out.p[0] = out.p[1] = out.p[2] = 0.0f;
+    out.normal[0] = out.normal[1] = out.normal[2] = 0.0f;
+    out.u = out.v = 0.0f;
+    if (h.slot >= 0) {
+        Surf s = surface_at(sc, vw, r, h);
+        out.prim = s.rec.w;
+        out.front_face = s.front ? 1 : 0;
+        out.t = h.t;
+        out.p[0] = s.p.x;
+        out.p[1] = s.p.y;
+        out.p[2] = s.p.z;
+        out.normal[0] = s.n.x;
+        out.normal[1] = s.n.y;
+        out.normal[2] = s.n.z;
+        if (RT_KIND_PRIM(s.rec.x) == RT_PRIM_SPHERE) { // sphere.h:70
+            sphere_uv(s.outward, out.u, out.v);
+        } else {
+            out.u = s.u;
+            out.v = s.v;
+        }
+    }
+    return out;
+}
+
+// Closest hit for a batch of rays, one whole ray per lane, scene read from global memory.
 template <int TRAV>
 __global__ void __launch_bounds__(RT_TRACE_THREADS)
 trace_batch(DevScene sc, const rt_ray *rays, long long n_rays, float tmin, float tmax, rt_hit *hits) {
-    __shared__ int stack_mem[RT_STACK_DEPTH * RT_TRACE_THREADS];
-    int *stack = stack_mem + threadIdx.x;
+    extern __shared__ f4 smem[];
+    const TravStack<int> st = lane_stack<int, false>(smem, sc, sc.stack_cap, nullptr);
     const SceneView vw = global_view(sc);
     Cnt<false> cn;
     for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < n_rays;
@@ -578,33 +635,92 @@ trace_batch(DevScene sc, const rt_ray *rays, long long n_rays, float tmin, float
         if constexpr (TRAV == TRAV_LINEAR)
             h = trace_linear<false>(sc, vw, r, tmin, tmax, cn);
         else
-            h = trace_bvh<false, int>(sc, vw, r, tmin, tmax, stack, RT_TRACE_THREADS, cn);
-        rt_hit out;
-        out.prim = -1;
-        out.front_face = 0;
-        out.t = 0.0f;
-        out.p[0] = out.p[1] = out.p[2] = 0.0f;
-        out.normal[0] = out.normal[1] = out.normal[2] = 0.0f;
-        out.u = out.v = 0.0f;
-        if (h.slot >= 0) {
-            Surf s = surface_at(sc, vw, r, h);
-            out.prim = s.rec.w;
-            out.front_face = s.front ? 1 : 0;
-            out.t = h.t;
-            out.p[0] = s.p.x;
-            out.p[1] = s.p.y;
-            out.p[2] = s.p.z;
-            out.normal[0] = s.n.x;
-            out.normal[1] = s.n.y;
-            out.normal[2] = s.n.z;
-            if (RT_KIND_PRIM(s.rec.x) == RT_PRIM_SPHERE) { // sphere.h:70
-                sphere_uv(s.outward, out.u, out.v);
-            } else {
-                out.u = s.u;
-                out.v = s.v;
-            }
+            h = trace_bvh<false, int, false>(sc, vw, r, tmin, tmax, st, cn);
+        hits[k] = make_hit_record(sc, vw, r, h);
+    }
+}
+
+// The same query through the render kernel's own traversal: the launch shape, the LDS copy of
+// the scene (or of the tree's top), the 16-bit / spilling stacks and the decoupled scheduling of
+// render_mega_bvh (wave_traverse: blocks of node steps, parked leaves), with the caller's rays
+// in place of paths.  A wave takes 64 consecutive rays at a time from a global counter; lanes
+// whose ray is done write its record and take the next one.
+template <bool LDS_SCENE>
+__global__ void __launch_bounds__(RT_MEGA_MAX_THREADS, RT_MEGA_WAVES_PER_SIMD)
+trace_sched(DevScene sc, RenderParams rp, const rt_ray *rays, long long n_rays, float tmin, float tmax, rt_hit *hits) {
+    extern __shared__ f4 smem[];
+    SceneView vw = global_view(sc);
+    f4 *free_lds = smem;
+    if constexpr (LDS_SCENE) free_lds = stage_scene(sc, smem, vw);
+    using StackT = typename std::conditional<LDS_SCENE, short, int>::type;
+    if constexpr (!LDS_SCENE) {
+        stage_to_lds(free_lds, sc.nodes, sc.n_top * 8);
+        vw.top = free_lds;
+        vw.n_top = sc.n_top;
+        free_lds += (size_t)sc.n_top * 8;
+        __syncthreads();
+    }
+    constexpr bool SPILL = !LDS_SCENE;
+    const TravStack<StackT> st = lane_stack<StackT, SPILL>(free_lds, sc, rp.stack_lds_entries, rp.stack_spill);
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lane_mask_lt = (1ull << lane) - 1ull;
+    const unsigned long long n_batches = (unsigned long long)((n_rays + 63) / 64);
+    unsigned long long *next_batch = reinterpret_cast<unsigned long long *>(rp.next_chunk);
+    long long k = 0, k_end = 0; // the wave's current batch of rays
+    bool exhausted = false;
+    int state = ST_IDLE, pend = 0;
+    long long mine = -1;
+    Ray ray;
+    Trav tv;
+    Cnt<false> cn;
+    SchedStats ss;
+    for (;;) {
+        if (state == ST_READY) {
+            TraceHit h;
+            h.t = tv.best_t;
+            h.slot = tv.best_slot;
+            hits[mine] = make_hit_record(sc, vw, ray, h);
+            state = ST_IDLE;
         }
-        hits[k] = out;
+        // idle lanes take the next rays of the batch; an empty batch is replaced first
+        unsigned long long need = __ballot(state == ST_IDLE);
+        bool want = state == ST_IDLE;
+        for (int pass = 0; pass < 2 && need != 0ull && !exhausted; pass++) {
+            if (k >= k_end) {
+                unsigned long long b = 0;
+                if (lane == 0) b = atomicAdd(next_batch, 1ull);
+                b = ((unsigned long long)wave_bcast32((unsigned)(b >> 32)) << 32) | wave_bcast32((unsigned)b);
+                if (b >= n_batches) {
+                    exhausted = true;
+                    break;
+                }
+                k = (long long)b * 64;
+                k_end = k + 64 < n_rays ? k + 64 : n_rays;
+            }
+            const long long avail = k_end - k;
+            const int r = __popcll(need & lane_mask_lt);
+            const bool take = want && r < avail;
+            if (take) {
+                mine = k + r;
+                const rt_ray in = rays[mine];
+                ray.o = mk(in.orig[0], in.orig[1], in.orig[2]);
+                ray.d = mk(in.dir[0], in.dir[1], in.dir[2]);
+                ray.tm = in.tm;
+                trav_begin(tv, ray, tmax);
+                pend = 0;
+                state = ST_TRAV;
+                want = false;
+            }
+            const int n_need = __popcll(need);
+            k += n_need < avail ? n_need : avail;
+            need &= ~__ballot(take);
+        }
+        if (!__any(state != ST_IDLE)) {
+            if (exhausted) break;
+            continue;
+        }
+        wave_traverse<LDS_SCENE, false, StackT, SPILL>(state, tv, pend, ray, sc, vw, st, tmin, rp.min_ready, rp.leaf_min,
+                                                       rp.blocked_min, !exhausted, cn, ss);
     }
 }
 
@@ -704,6 +820,14 @@ hipError_t RT_LAUNCH_NAME(set_mega_lds_limit)(int bytes) {
     RT_SET2(false, true)
     RT_SET2(false, false)
 #undef RT_SET2
+#ifndef RT_LEAN
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void *)trace_sched<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void *)trace_sched<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void *)trace_batch<TRAV_BVH>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+#endif
     return e;
 }
 
@@ -728,11 +852,25 @@ hipError_t launch_trace(const DevScene &sc, const rt_ray *rays, long long n, flo
                         rt_hit *hits, hipStream_t stream) {
     long long want = (n + RT_TRACE_THREADS - 1) / RT_TRACE_THREADS;
     int grid = (int)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
+    const int lds = sc.traversal == TRAV_LINEAR ? 16 : sc.stack_cap * RT_TRACE_THREADS * (int)sizeof(int);
     if (sc.traversal == TRAV_LINEAR)
-        hipLaunchKernelGGL((trace_batch<TRAV_LINEAR>), dim3(grid), dim3(RT_TRACE_THREADS), 0, stream, sc, rays,
+        hipLaunchKernelGGL((trace_batch<TRAV_LINEAR>), dim3(grid), dim3(RT_TRACE_THREADS), lds, stream, sc, rays,
                            n, tmin, tmax, hits);
     else
-        hipLaunchKernelGGL((trace_batch<TRAV_BVH>), dim3(grid), dim3(RT_TRACE_THREADS), 0, stream, sc, rays, n,
+        hipLaunchKernelGGL((trace_batch<TRAV_BVH>), dim3(grid), dim3(RT_TRACE_THREADS), lds, stream, sc, rays, n,
+                           tmin, tmax, hits);
+    return hipGetLastError();
+}
+
+// rp: stack_lds_entries, stack_spill, min_ready / leaf_min / blocked_min and next_chunk (an
+// 8-byte counter, zeroed) are used; lg is the scene's render geometry.
+hipError_t launch_trace_sched(const DevScene &sc, const RenderParams &rp, const LaunchGeom &lg, const rt_ray *rays,
+                              long long n, float tmin, float tmax, rt_hit *hits, hipStream_t stream) {
+    if (lg.lds_scene)
+        hipLaunchKernelGGL((trace_sched<true>), dim3(lg.grid), dim3(lg.block), lg.lds_bytes, stream, sc, rp, rays, n,
+                           tmin, tmax, hits);
+    else
+        hipLaunchKernelGGL((trace_sched<false>), dim3(lg.grid), dim3(lg.block), lg.lds_bytes, stream, sc, rp, rays, n,
                            tmin, tmax, hits);
     return hipGetLastError();
 }

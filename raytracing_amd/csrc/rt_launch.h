@@ -35,6 +35,8 @@ struct RenderParams {
     int pixel_major;               // order of the units: 0 sample-major, 1 pixel-major
     const unsigned *strip_order;   // pixel-major: the strips in the order they are handed out (null: as they lie)
     int ring_f4;                   // camera-ray rings (LaunchGeom::ring): their offset in dynamic LDS, 16-byte words
+    int stack_lds_entries;         // BVH scenes: stack entries per lane kept in LDS
+    int *stack_spill;              // ... the rest: [block][entry][lane of the block] (null: none)
     rtc::f4 *stage;                // [sample_count][n_pixels] {r g b rays}
     unsigned *next_chunk;          // pool counter, zeroed before the launch
     rtc::Counters *counters;       // non-null: count tests (instrumented kernel variant)
@@ -63,6 +65,9 @@ struct LaunchGeom {
     int lds_bytes;
     bool lds_scene;  // slots + nodes are staged into LDS
     int lds_records; // ... and so are the per-slot records and the texture table
+    int lds_perlins = 0; // ... and the Perlin tables
+    int stack_cap = 0;         // entries a traversal stack needs for this scene's tree
+    int stack_lds_entries = 0; // ... of which this many live in LDS (the rest spills to global memory)
     // decoupled kernel: every wave keeps the 64 camera rays of its current unit in LDS (generated
     // by all lanes at once when the unit is taken; idle lanes then only fetch theirs)
     bool ring = false;
@@ -103,7 +108,7 @@ size_t order_strips_tmp_bytes(unsigned n);
 hipError_t fill_iota(unsigned *v, unsigned n, hipStream_t stream);
 hipError_t order_strips(const unsigned *cost, const unsigned *iota, unsigned n, unsigned *cost_sorted, unsigned *order,
                         void *tmp, size_t tmp_bytes, hipStream_t stream);
-hipError_t build_lbvh(const float *boxes, const int *types, int n, float **d_nodes_out, int *leaf_order,
+hipError_t build_lbvh(const float *boxes, const int *types, int n, float *nodes_out, int *leaf_order,
                       int *inner_levels);
 hipError_t static_scratch_setup(int device); // the device must be current
 void *static_scratch(int device);
@@ -111,4 +116,6 @@ hipError_t launch_tonemap(const float *accum, long long n_components, float scal
                           hipStream_t stream);
 hipError_t launch_trace(const rtc::DevScene &sc, const rt_ray *rays, long long n, float tmin, float tmax,
                         rt_hit *hits, hipStream_t stream);
+hipError_t launch_trace_sched(const rtc::DevScene &sc, const RenderParams &rp, const LaunchGeom &lg, const rt_ray *rays,
+                              long long n, float tmin, float tmax, rt_hit *hits, hipStream_t stream);
 } // namespace rtl

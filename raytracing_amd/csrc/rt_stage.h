@@ -12,8 +12,8 @@ __device__ __forceinline__ void stage_to_lds(f4 *dst, const f4 *src, int n) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
 }
 
-// Stages slots, nodes, the per-slot records and the texture table into LDS (the layout
-// matches scene_lds_bytes() in rt_host.cpp); returns the first free 16-byte word.
+// Stages slots, nodes, the per-slot records, the texture table and the Perlin tables into LDS
+// (the layout matches choose_geom() in rt_host.cpp); returns the first free 16-byte word.
 __device__ __forceinline__ f4 *stage_scene(const DevScene &sc, f4 *smem, SceneView &v) {
     int n_slot_words = sc.n_slots * sc.slot_f4;
     int n_node_words = sc.n_nodes * 4;
@@ -37,8 +37,28 @@ __device__ __forceinline__ f4 *stage_scene(const DevScene &sc, f4 *smem, SceneVi
         v.textures = reinterpret_cast<const rt_texture *>(p);
         p += n_tex_words;
     }
+    if (sc.lds_perlins) { // noise textures gather from these tables 50 times per evaluation
+        const int n_perlin_words = sc.n_perlins * (int)(sizeof(DevPerlin) / sizeof(f4));
+        stage_to_lds(p, reinterpret_cast<const f4 *>(sc.perlins), n_perlin_words);
+        v.perlins = reinterpret_cast<const DevPerlin *>(p);
+        p += n_perlin_words;
+    }
     __syncthreads();
     return p;
+}
+
+// This lane's traversal stack: a column of the workgroup's [entry][lane] array that starts at
+// `lds_words`, and (SPILL) a column of the same shape in global memory for the entries beyond.
+template <typename T, bool SPILL>
+__device__ __forceinline__ TravStack<T> lane_stack(f4 *lds_words, const DevScene &sc, int lds_entries, int *spill) {
+    TravStack<T> st;
+    st.lds = reinterpret_cast<T *>(lds_words) + threadIdx.x;
+    st.stride = (int)blockDim.x;
+    st.lds_end = lds_entries * (int)blockDim.x;
+    st.spill = nullptr;
+    if constexpr (SPILL)
+        st.spill = spill + (size_t)blockIdx.x * (size_t)(sc.stack_cap - lds_entries) * blockDim.x + threadIdx.x;
+    return st;
 }
 
 } // namespace rtc

@@ -122,7 +122,7 @@ __global__ void wf_advance(unsigned *cnt) { cnt[C_POOL] += cnt[C_GEN_COUNT]; }
 // and, per queue position, the key of the queue the ray goes to next.
 template <int TRAV, bool LDS_SCENE>
 __global__ void __launch_bounds__(RT_MEGA_MAX_THREADS, RT_MEGA_WAVES_PER_SIMD)
-wf_trace(DevScene sc, WfBuffers wf, const int *q_trace_cur) {
+wf_trace(DevScene sc, WfBuffers wf, const int *q_trace_cur, int stack_lds_entries, int *stack_spill) {
     extern __shared__ f4 smem[];
     SceneView vw = global_view(sc);
     f4 *free_lds = smem;
@@ -130,8 +130,8 @@ wf_trace(DevScene sc, WfBuffers wf, const int *q_trace_cur) {
     if (blockIdx.x * blockDim.x >= n) return; // nothing for this workgroup: skip the staging
     if constexpr (LDS_SCENE) free_lds = stage_scene(sc, smem, vw);
     using StackT = typename std::conditional<LDS_SCENE, short, int>::type;
-    StackT *stack = reinterpret_cast<StackT *>(free_lds) + threadIdx.x;
-    const int stack_stride = blockDim.x;
+    constexpr bool SPILL = !LDS_SCENE;
+    const TravStack<StackT> stk = lane_stack<StackT, SPILL>(free_lds, sc, stack_lds_entries, stack_spill);
     Cnt<false> cn;
     const unsigned stride = gridDim.x * blockDim.x;
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -146,7 +146,7 @@ wf_trace(DevScene sc, WfBuffers wf, const int *q_trace_cur) {
         if constexpr (TRAV == TRAV_LINEAR)
             h = trace_linear<false>(sc, vw, r, 0.001f, RT_INF, cn);
         else
-            h = trace_bvh<false, StackT>(sc, vw, r, 0.001f, RT_INF, stack, stack_stride, cn);
+            h = trace_bvh<false, StackT, SPILL>(sc, vw, r, 0.001f, RT_INF, stk, cn);
         // the first 8 bytes of the auxiliary record: {t, slot}
         *reinterpret_cast<float2 *>(&wf.aux[slot]) = float2{h.t, __builtin_bit_cast(float, h.slot)};
         wf.key[i] = h.slot < 0 ? (int)Q_MISS : RT_KIND_MAT(vw.rec_i[h.slot].x);
@@ -276,14 +276,14 @@ hipError_t render_wavefront(const DevScene &sc, const DevCamera &cam, const Rend
             hipLaunchKernelGGL(wf_advance, dim3(1), dim3(1), 0, stream, wf.cnt);
             if (sc.traversal == TRAV_LINEAR) {
                 if (lg.lds_scene)
-                    hipLaunchKernelGGL((wf_trace<TRAV_LINEAR, true>), dim3(lg.grid), dim3(lg.block), lg.lds_bytes, stream, sc, wf, cur);
+                    hipLaunchKernelGGL((wf_trace<TRAV_LINEAR, true>), dim3(lg.grid), dim3(lg.block), lg.lds_bytes, stream, sc, wf, cur, rp.stack_lds_entries, rp.stack_spill);
                 else
-                    hipLaunchKernelGGL((wf_trace<TRAV_LINEAR, false>), dim3(lg.grid), dim3(lg.block), lg.lds_bytes, stream, sc, wf, cur);
+                    hipLaunchKernelGGL((wf_trace<TRAV_LINEAR, false>), dim3(lg.grid), dim3(lg.block), lg.lds_bytes, stream, sc, wf, cur, rp.stack_lds_entries, rp.stack_spill);
             } else {
                 if (lg.lds_scene)
-                    hipLaunchKernelGGL((wf_trace<TRAV_BVH, true>), dim3(lg.grid), dim3(lg.block), lg.lds_bytes, stream, sc, wf, cur);
+                    hipLaunchKernelGGL((wf_trace<TRAV_BVH, true>), dim3(lg.grid), dim3(lg.block), lg.lds_bytes, stream, sc, wf, cur, rp.stack_lds_entries, rp.stack_spill);
                 else
-                    hipLaunchKernelGGL((wf_trace<TRAV_BVH, false>), dim3(lg.grid), dim3(lg.block), lg.lds_bytes, stream, sc, wf, cur);
+                    hipLaunchKernelGGL((wf_trace<TRAV_BVH, false>), dim3(lg.grid), dim3(lg.block), lg.lds_bytes, stream, sc, wf, cur, rp.stack_lds_entries, rp.stack_spill);
             }
             hipLaunchKernelGGL(wf_classify, dim3(big_grid), dim3(1024), 0, stream, wf, cur);
             hipLaunchKernelGGL(wf_shade, dim3(big_grid), dim3(1024), 0, stream, sc, cam, rp, wf, next);

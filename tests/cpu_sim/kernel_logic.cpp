@@ -9,6 +9,7 @@
 #include "rt_core.h"
 #include "rt_flatten.h"
 
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -31,7 +32,6 @@ void *sim_scene_create(const rt_scene_desc *d, uint32_t flags) {
         delete s;
         return nullptr;
     }
-    s->perl.assign(d->perlins, d->perlins + d->n_perlins);
     s->imgs.assign(d->images, d->images + d->n_images);
     s->texels.assign(d->texels, d->texels + d->n_texel_bytes);
     DevScene &dv = s->dev;
@@ -44,7 +44,8 @@ void *sim_scene_create(const rt_scene_desc *d, uint32_t flags) {
     dv.nodes = s->hs.nodes.data();
     dv.xf = s->hs.xf.data();
     dv.chain_first = s->hs.chain_first.data();
-    dv.perlins = s->perl.data();
+    dv.perlins = s->hs.perlins.data();
+    dv.n_perlins = (int)s->hs.perlins.size();
     dv.images = s->imgs.data();
     dv.texels = s->texels.data();
     dv.n_slots = s->hs.n_prims;
@@ -52,10 +53,53 @@ void *sim_scene_create(const rt_scene_desc *d, uint32_t flags) {
     dv.slot_f4 = s->hs.slot_f4;
     dv.traversal = s->hs.linear ? TRAV_LINEAR : TRAV_BVH;
     dv.n_chains = d->n_chains;
-    dv.n_xf_ops = (int)(s->hs.xf.size() / 3);
+    dv.n_xf_ops = (int)(s->hs.xf.size() / RT_XF_F4);
+    dv.stack_cap = RT_STACK_CAP(s->hs.bvh_depth);
+    {   // as the library chooses it for a scene that stays in global memory
+        int bits = 1;
+        while ((1ll << bits) < std::max<long long>(dv.n_nodes, 2ll * dv.n_slots)) bits++;
+        dv.ref_bits = std::max(16, std::min(32, bits + 1));
+    }
     return s;
 }
 void sim_scene_destroy(void *s) { delete (SimScene *)s; }
+
+// Which of the kernels' stack variants the traversals below use: 0 = 32-bit entries, all in one
+// column; 1 = 16-bit entries (scenes small enough for them: the variant of scenes held in LDS);
+// 2 = 32-bit entries of which only the first four stay in the first column (the spilling variant
+// of deep trees read from HBM).
+static int g_stack_mode = 0;
+void sim_set_stack_mode(int mode) { g_stack_mode = mode; }
+
+extern "C++" {
+namespace {
+struct SimStacks {
+    std::vector<int> a, b;
+    std::vector<short> h;
+    TravStack<int> st32;
+    TravStack<short> st16;
+    explicit SimStacks(const DevScene &sc) : a(sc.stack_cap + 8), b(sc.stack_cap + 8), h(sc.stack_cap + 8) {
+        st32.lds = a.data();
+        st32.spill = b.data();
+        st32.stride = 1;
+        st32.lds_end = g_stack_mode == 2 ? 4 : sc.stack_cap + 8;
+        st16.lds = h.data();
+        st16.spill = nullptr;
+        st16.stride = 1;
+        st16.lds_end = sc.stack_cap + 8;
+    }
+};
+template <bool COUNT> TraceHit sim_trace_bvh(DevScene sc, const SceneView &vw, const Ray &r, float tmin, float tmax,
+                                             SimStacks &k, Cnt<COUNT> &cn) {
+    if (g_stack_mode == 1 && sc.n_nodes < 32768 && sc.n_slots < 16384) {
+        sc.ref_bits = 16;
+        return trace_bvh<COUNT, short, false>(sc, vw, r, tmin, tmax, k.st16, cn);
+    }
+    if (g_stack_mode == 2) return trace_bvh<COUNT, int, true>(sc, vw, r, tmin, tmax, k.st32, cn);
+    return trace_bvh<COUNT, int, false>(sc, vw, r, tmin, tmax, k.st32, cn);
+}
+} // namespace
+} // extern "C++"
 int sim_scene_nodes(void *s) { return ((SimScene *)s)->hs.n_nodes; }
 int sim_scene_depth(void *s) { return ((SimScene *)s)->hs.bvh_depth; }
 
@@ -64,7 +108,7 @@ void sim_trace_batch(void *scene, const rt_ray *rays, long long n, float tmin, f
     SimScene *s = (SimScene *)scene;
     const DevScene &sc = s->dev;
     const SceneView vw = global_view(sc);
-    int stack[RT_STACK_DEPTH + 8];
+    SimStacks stacks(sc);
     Cnt<true> cn;
     for (long long k = 0; k < n; k++) {
         Ray r;
@@ -72,7 +116,7 @@ void sim_trace_batch(void *scene, const rt_ray *rays, long long n, float tmin, f
         r.d = mk(rays[k].dir[0], rays[k].dir[1], rays[k].dir[2]);
         r.tm = rays[k].tm;
         TraceHit h = sc.traversal == TRAV_LINEAR ? trace_linear<true>(sc, vw, r, tmin, tmax, cn)
-                                                 : trace_bvh<true, int>(sc, vw, r, tmin, tmax, stack, 1, cn);
+                                                 : sim_trace_bvh<true>(sc, vw, r, tmin, tmax, stacks, cn);
         rt_hit out;
         memset(&out, 0, sizeof(out));
         out.prim = -1;
@@ -103,7 +147,7 @@ void sim_render(void *scene, const rt_camera_desc *cam, int sample_begin, int sa
     dc.defocus_angle = cam->defocus_angle;
     dc.max_depth = cam->max_depth;
     const SceneView vw = global_view(sc);
-    int stack[RT_STACK_DEPTH + 8];
+    SimStacks stacks(sc);
     Cnt<false> cn;
     unsigned long long rays = 0;
     int npix = dc.f.image_width * dc.f.image_height;
@@ -113,11 +157,12 @@ void sim_render(void *scene, const rt_camera_desc *cam, int sample_begin, int sa
             PathState ps = path_start(dc, seed, (unsigned)pix, pix % dc.f.image_width, pix / dc.f.image_width,
                                       (unsigned)(sample_begin + sidx));
             unsigned n_rays = 0;
-            for (;;) {
-                bool cont = sc.traversal == TRAV_LINEAR
-                                ? path_step<TRAV_LINEAR, false, int>(sc, vw, dc, ps, stack, 1, n_rays, cn)
-                                : path_step<TRAV_BVH, false, int>(sc, vw, dc, ps, stack, 1, n_rays, cn);
-                if (!cont) break;
+            for (;;) { // path_step (rt_core.h) with the stack variant under test
+                if (ps.depth <= 0) break;
+                n_rays++;
+                TraceHit h = sc.traversal == TRAV_LINEAR ? trace_linear<false>(sc, vw, ps.ray, 0.001f, RT_INF, cn)
+                                                         : sim_trace_bvh<false>(sc, vw, ps.ray, 0.001f, RT_INF, stacks, cn);
+                if (!path_after_trace<false>(sc, vw, dc, ps, h, cn)) break;
             }
             rays += n_rays;
             r += ps.L.x; g += ps.L.y; b += ps.L.z;

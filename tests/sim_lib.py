@@ -26,8 +26,15 @@ def lib():
                                       C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
         L.sim_render.argtypes = [C.c_void_p, C.POINTER(abi.CameraDesc), C.c_int, C.c_int, C.c_uint32,
                                  C.c_void_p, C.POINTER(C.c_ulonglong)]
+        L.sim_set_stack_mode.argtypes = [C.c_int]
         _lib = L
     return _lib
+
+
+def set_stack_mode(mode):
+    """0: 32-bit stack entries in one column; 1: 16-bit entries (small scenes); 2: 32-bit entries
+    that spill to a second column after four (the kernels' variant for deep trees in HBM)."""
+    lib().sim_set_stack_mode(mode)
 
 
 class SimScene:

@@ -163,9 +163,16 @@ def test_kernel_logic_matches_reference_records(scene):
     rays, ref_hits, tmin, tmax = O.load_rays_file(os.path.join(GOLDEN, scene + ".rays"))
     # (cornell_box under a forced BVH: its rotated / scaled boxes are tested in object space at
     # the leaves, exactly like the linear scan, so that is bit-exact as well)
-    for flags in (0, abi.RT_SCENE_FORCE_LINEAR, abi.RT_SCENE_FORCE_BVH):
-        hits, _, _ = S.SimScene(arrays, flags).trace(rays, tmin, tmax)
-        assert hits.tobytes() == ref_hits.tobytes(), f"flags {flags}"
+    # ... with each of the kernels' stack variants: 32-bit entries, the 16-bit entries of scenes held
+    # in LDS, and 32-bit entries that overflow into a second column (deep trees read from HBM)
+    try:
+        for flags in (0, abi.RT_SCENE_FORCE_LINEAR, abi.RT_SCENE_FORCE_BVH):
+            for mode in ((0,) if flags == abi.RT_SCENE_FORCE_LINEAR else (0, 1, 2)):
+                S.set_stack_mode(mode)
+                hits, _, _ = S.SimScene(arrays, flags).trace(rays, tmin, tmax)
+                assert hits.tobytes() == ref_hits.tobytes(), f"flags {flags} stack mode {mode}"
+    finally:
+        S.set_stack_mode(0)
 
 
 def test_kernel_logic_bvh_never_drops_a_hit():
@@ -184,11 +191,18 @@ def test_kernel_logic_bvh_never_drops_a_hit():
     rays["dir"][1000:2000, 1] = 0
     rays["dir"][2000:2500, [0, 2]] = 0
     sim = S.SimScene(arrays)
-    assert sim.n_nodes == 484 and sim.depth <= 30
-    hits, box, prim = sim.trace(rays)
+    # 4-wide tree collapsed from the binary one (484 inner nodes): between a third and all of them
+    assert 484 / 3 <= sim.n_nodes < 300 and sim.depth <= 12
     ref, _ = O.OracleScene(arrays).trace(rays, 0.001, np.inf, O.TRACE_BAKED)  # scan of all 485
-    assert np.array_equal(hits["prim"], ref["prim"]) and np.array_equal(hits["t"], ref["t"])
-    assert prim / n < 5  # the tree culls: a handful of exact tests per ray instead of 485
+    try:
+        for mode in (0, 1, 2):
+            S.set_stack_mode(mode)
+            hits, box, prim = sim.trace(rays)
+            assert np.array_equal(hits["prim"], ref["prim"]) and np.array_equal(hits["t"], ref["t"]), mode
+            assert prim / n < 5  # the tree culls: a handful of exact tests per ray instead of 485
+            assert box / n < 40
+    finally:
+        S.set_stack_mode(0)
 
 
 def instanced_scene(n=96, seed=11):
@@ -251,7 +265,7 @@ def test_kernel_logic_instances_inside_a_bvh():
     ref, _ = O.OracleScene(arrays).trace(rays, 0.001, np.inf, O.TRACE_REFERENCE)
     assert (ref["prim"] >= 0).mean() > 0.05
     sim = S.SimScene(arrays)
-    assert sim.n_nodes == len(arrays.prims) - 1
+    assert (len(arrays.prims) - 1) / 3 <= sim.n_nodes <= len(arrays.prims) - 1
     hits, _, prim_tests = sim.trace(rays)
     assert hits.tobytes() == ref.tobytes()
     assert prim_tests / len(rays) < 12

@@ -1,4 +1,6 @@
-"""GPU parity of the closest-hit entry point (rt_trace_batch through the C ABI).
+"""GPU parity of the closest-hit entry points (rt_trace_batch and rt_trace_batch_sched through
+the C ABI; the latter answers the query with the render kernel's own traversal: its launch shape,
+LDS copy of the scene, stacks and interleaved scheduling of node steps and parked leaves).
 
 Bar: hit / miss and primitive ids bit-exact against the reference's own records
 (tests/golden/*.rays, written by the unmodified reference); t, p and the normal
@@ -27,7 +29,13 @@ def test_trace_matches_reference_records(scene):
     arrays, cam, _ = load_scene(scene)
     rays, ref_hits, tmin, tmax = O.load_rays_file(os.path.join(GOLDEN, scene + ".rays"))
     sc = B.Scene(arrays)
-    hits = sc.trace(rays, tmin, tmax)
+    for sched in (False, True):
+        hits = sc.trace(rays, tmin, tmax, sched=sched)
+        _check_records(hits, ref_hits)
+    sc.close()
+
+
+def _check_records(hits, ref_hits):
     assert np.array_equal(hits["prim"], ref_hits["prim"]), "hit/miss or primitive id differs"
     m = ref_hits["prim"] >= 0
     assert np.array_equal(hits["front_face"][m], ref_hits["front_face"][m])
@@ -36,7 +44,30 @@ def test_trace_matches_reference_records(scene):
     assert np.array_equal(hits["normal"][m], ref_hits["normal"][m])
     assert np.abs(hits["u"][m] - ref_hits["u"][m]).max(initial=0) <= 2e-6
     assert np.abs(hits["v"][m] - ref_hits["v"][m]).max(initial=0) <= 2e-6
-    sc.close()
+
+
+@pytest.mark.parametrize("scene", SCENES)
+def test_reference_records_through_the_render_kernels_traversal(scene, monkeypatch):
+    """The reference's own ray records through the traversal the benchmarked kernel runs
+    (rt_trace_batch_sched), with a tree forced over every scene: the variant that keeps the scene
+    in LDS (16-bit stacks), the one that reads it from HBM (32-bit stacks, top of the tree in
+    LDS), and the latter with only four stack entries in LDS so that stacks overflow into global
+    memory.  Bit-exact: hit / miss, primitive, t, p, normal, face."""
+    B = _binding()
+    arrays, cam, _ = load_scene(scene)
+    rays, ref_hits, tmin, tmax = O.load_rays_file(os.path.join(GOLDEN, scene + ".rays"))
+    for flags, lds_stack in ((abi.RT_SCENE_FORCE_BVH, None), (abi.RT_SCENE_FORCE_BVH | abi.RT_SCENE_FORCE_GLOBAL, None),
+                             (abi.RT_SCENE_FORCE_BVH | abi.RT_SCENE_FORCE_GLOBAL, "4")):
+        if lds_stack:
+            monkeypatch.setenv("RT_AMD_LDS_STACK", lds_stack)  # read by rt_scene_create
+        sc = B.Scene(arrays, flags=flags)
+        if lds_stack:
+            monkeypatch.delenv("RT_AMD_LDS_STACK")
+        info = sc.info()
+        if len(arrays.prims) >= 2:
+            assert info.n_nodes > 0 and info.lds_resident == (0 if flags & abi.RT_SCENE_FORCE_GLOBAL else 1)
+        _check_records(sc.trace(rays, tmin, tmax, sched=True), ref_hits)
+        sc.close()
 
 
 @pytest.mark.parametrize("scene", ["bouncing_spheres", "quads", "simple_light", "checkered_spheres", "cornell_box"])
@@ -48,10 +79,11 @@ def test_forced_bvh_and_forced_linear_agree_with_oracle(scene):
     for flags in (abi.RT_SCENE_FORCE_BVH, abi.RT_SCENE_FORCE_LINEAR,
                   abi.RT_SCENE_FORCE_BVH | abi.RT_SCENE_FORCE_GLOBAL):
         sc = B.Scene(arrays, flags=flags)
-        hits = sc.trace(rays, tmin, tmax)
-        assert np.array_equal(hits["prim"], ref_hits["prim"])
-        m = ref_hits["prim"] >= 0
-        assert np.array_equal(hits["t"][m], ref_hits["t"][m])
+        for sched in (False, True):
+            hits = sc.trace(rays, tmin, tmax, sched=sched)
+            assert np.array_equal(hits["prim"], ref_hits["prim"])
+            m = ref_hits["prim"] >= 0
+            assert np.array_equal(hits["t"][m], ref_hits["t"][m])
         sc.close()
 
 
@@ -66,6 +98,7 @@ def test_instances_inside_a_bvh():
     ref, _ = O.OracleScene(arrays).trace(rays, 0.001, np.inf, O.TRACE_REFERENCE)
     for flags in (0, abi.RT_SCENE_FORCE_BVH | abi.RT_SCENE_FORCE_GLOBAL, abi.RT_SCENE_FORCE_LINEAR):
         sc = B.Scene(arrays, flags=flags)
+        assert sc.trace(rays, sched=True).tobytes() == sc.trace(rays).tobytes()
         hits = sc.trace(rays)
         assert np.array_equal(hits["prim"], ref["prim"])
         m = ref["prim"] >= 0
@@ -104,13 +137,15 @@ def test_large_random_batch_bouncing_spheres():
     rays["orig"] = o
     rays["dir"] = (tgt - o) * rng.uniform(0.2, 3, size=(n, 1))
     rays["tm"] = rng.uniform(0, 1, n)
-    sc = B.Scene(arrays)
-    hits = sc.trace(rays)
     osc = O.OracleScene(arrays)
     oh, _ = osc.trace(rays, 0.001, np.inf, O.TRACE_REFERENCE)
-    assert np.array_equal(hits["prim"], oh["prim"])
-    assert np.array_equal(hits["t"], oh["t"])
-    sc.close()
+    for flags in (0, abi.RT_SCENE_FORCE_GLOBAL):  # the render kernel's LDS and HBM variants
+        sc = B.Scene(arrays, flags=flags)
+        for sched in (False, True):
+            hits = sc.trace(rays, sched=sched)
+            assert np.array_equal(hits["prim"], oh["prim"]), (flags, sched)
+            assert np.array_equal(hits["t"], oh["t"]), (flags, sched)
+        sc.close()
 
 
 def test_edge_cases():
