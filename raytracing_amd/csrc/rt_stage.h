@@ -16,7 +16,7 @@ __device__ __forceinline__ void stage_to_lds(f4 *dst, const f4 *src, int n) {
 // (the layout matches choose_geom() in rt_host.cpp); returns the first free 16-byte word.
 __device__ __forceinline__ f4 *stage_scene(const DevScene &sc, f4 *smem, SceneView &v) {
     int n_slot_words = sc.n_slots * sc.slot_f4;
-    int n_node_words = sc.n_nodes * 4;
+    int n_node_words = sc.n_nodes * 8;
     int n_tex_words = (sc.n_textures * (int)sizeof(rt_texture) + 15) / 16;
     f4 *p = smem;
     stage_to_lds(p, sc.slots, n_slot_words);

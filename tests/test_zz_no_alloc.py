@@ -2,9 +2,9 @@
 the library's statically allocated device block) against rt_render_device, through the C ABI.
 No counterpart in the reference; the check is against this library's own entry point, which the
 other GPU tests pin to the oracle.  Bit-exact where both calls use one launch (integer ray
-counts aside, the image is a sum of fp32 records in sample order); 1e-6 relative where the
-static block forces more launches than rt_render_device needs (the per-launch partial sums are
-then added in a different grouping)."""
+counts aside, the image is a sum of fp32 records in sample order); within the rounding of the
+additions, 2 (spp - 1) 2^-24 relative, where the static block forces more launches than
+rt_render_device needs (the per-launch partial sums are then added in a different grouping)."""
 import numpy as np
 import pytest
 
@@ -51,7 +51,8 @@ def test_static_entry_point_matches_render_device_twice_in_a_row():
     n_px = big.image_width * big.image_height()
     spp = abi.RT_STATIC_MAX_PIXELS // n_px + 2
     a4, b4 = _pair(sc, big, spp, seed=7)
-    assert np.allclose(a4, b4, rtol=1e-6, atol=1e-6)
+    # (each grouping of spp fp32 additions is within (spp - 1) * 2^-24 of the exact sum)
+    assert np.allclose(a4, b4, rtol=2 * (spp - 1) * 2.0 ** -24, atol=1e-6)
     # accumulation: a second call adds to the image
     import torch
     acc = torch.zeros((small.image_height(), 96, 3), dtype=torch.float32, device="cuda:0")
