@@ -546,11 +546,16 @@ RT_HD bool box_hit(f3 c, f3 h, const BoxRay &b, float tmin, float tmax, float &t
 // wave touch consecutive banks / addresses.  Entries [0, lds_cap) live in LDS; scenes whose
 // tree is too deep for that keep the entries beyond in a second column in global memory (only
 // rays that have that many subtrees pending ever get there).
-template <typename T> struct TravStack {
+// STRIDE: elements between consecutive entries of a column (both columns), a compile-time
+// constant where the kernel's workgroup size is one (the entry offsets then fold into the
+// instructions' immediates); 0: taken from rt_stride.
+template <typename T, int STRIDE = 0> struct TravStack {
+    typedef T elem;
     T *lds;
-    int *spill;   // null: the LDS column holds the whole stack
-    int stride;   // elements between consecutive entries (both columns)
-    int lds_end;  // lds_cap * stride
+    int *spill;    // null: the LDS column holds the whole stack
+    int rt_stride; // used if STRIDE == 0
+    int lds_end;   // lds_cap * stride
+    RT_HD int stride() const { return STRIDE ? STRIDE : rt_stride; }
 };
 
 // BVH traversal as a resumable state machine, so that a wave can interleave the
@@ -586,12 +591,13 @@ template <typename T> RT_HD int stack_entry_ref(T e, int ref_bits) {
     const int sh = 32 - ref_bits;
     return ((int)e << sh) >> sh;
 }
-template <typename T, bool SPILL> RT_HD void trav_pop(Trav &tv, const TravStack<T> &st, int ref_bits) {
+template <class ST, bool SPILL> RT_HD void trav_pop(Trav &tv, const ST &st, int ref_bits) {
+    typedef typename ST::elem T;
     if (tv.sp == 0) {
         tv.ref = RT_TRAV_DONE;
         return;
     }
-    tv.sp -= st.stride;
+    tv.sp -= st.stride();
     if (!SPILL || tv.sp < st.lds_end)
         tv.ref = stack_entry_ref<T>(st.lds[tv.sp], ref_bits);
     else
@@ -611,9 +617,10 @@ RT_HD unsigned umax_(unsigned a, unsigned b) { return a > b ? a : b; }
 // above the stack's top: the farthest child lands lowest, the missed ones above the new top
 // where they do not count.  No branch depends on how many children were hit.
 // TOP: nodes [0, n_top) are read from `top` (the workgroup's LDS) instead of `nodes` (HBM).
-template <bool COUNT, typename T, bool TOP, bool SPILL>
-RT_HD void trav_inner(Trav &tv, const f4 *nodes, float tmin, const TravStack<T> &st, int ref_bits, Cnt<COUNT> &cn,
+template <bool COUNT, class ST, bool TOP, bool SPILL>
+RT_HD void trav_inner(Trav &tv, const f4 *nodes, float tmin, const ST &st, int ref_bits, Cnt<COUNT> &cn,
                       const f4 *top = nullptr, int n_top = 0) {
+    typedef typename ST::elem T;
     f4 q0, q1, q2, q3, q4, q5, q6;
     if (TOP && tv.ref < n_top) { // two explicit paths: LDS reads and global loads, no flat addressing
         const f4 *n = top + (size_t)tv.ref * 8;
@@ -640,7 +647,7 @@ RT_HD void trav_inner(Trav &tv, const f4 *nodes, float tmin, const TravStack<T> 
     const unsigned m1 = umin_(hi01, hi23), m2 = umax_(lo01, lo23);
     const unsigned a1 = umax_(m1, m2), a2 = umin_(m1, m2);
     const int n_hit = (int)h0 + (int)h1 + (int)h2 + (int)h3;
-    const int sp = tv.sp, sd = st.stride;
+    const int sp = tv.sp, sd = st.stride();
     if (!SPILL || sp + 3 * sd < st.lds_end) {
         st.lds[sp] = (T)a0;
         st.lds[sp + sd] = (T)a1;
@@ -658,7 +665,7 @@ RT_HD void trav_inner(Trav &tv, const f4 *nodes, float tmin, const TravStack<T> 
         }
     }
     tv.sp = sp + n_hit * sd;
-    trav_pop<T, SPILL>(tv, st, ref_bits);
+    trav_pop<ST, SPILL>(tv, st, ref_bits);
 }
 // Exact test of one leaf against the current best (ties included).
 template <bool COUNT>
@@ -707,17 +714,17 @@ RT_HD void trav_test_leaf(Trav &tv, int leaf_ref, const DevScene &sc, const Scen
 }
 
 // Whole traversal of one ray.
-template <bool COUNT, typename T, bool SPILL = false>
+template <bool COUNT, class ST, bool SPILL = false>
 RT_HD TraceHit trace_bvh(const DevScene &sc, const SceneView &v, const Ray &r, float tmin, float tmax,
-                         const TravStack<T> &st, Cnt<COUNT> &cn) {
+                         const ST &st, Cnt<COUNT> &cn) {
     Trav tv;
     trav_begin(tv, r, tmax);
     while (tv.ref != RT_TRAV_DONE) {
         if (tv.ref >= 0) {
-            trav_inner<COUNT, T, false, SPILL>(tv, v.nodes, tmin, st, sc.ref_bits, cn);
+            trav_inner<COUNT, ST, false, SPILL>(tv, v.nodes, tmin, st, sc.ref_bits, cn);
         } else {
             trav_test_leaf<COUNT>(tv, tv.ref, sc, v, r, tmin, cn);
-            trav_pop<T, SPILL>(tv, st, sc.ref_bits);
+            trav_pop<ST, SPILL>(tv, st, sc.ref_bits);
         }
     }
     TraceHit best;
@@ -986,16 +993,16 @@ RT_HD bool path_after_trace(const DevScene &sc, const SceneView &vw, const DevCa
 
 // One whole segment of ray_color: trace, then miss / emit / scatter.  Returns true
 // while the path continues; when it returns false ps.L holds the path's radiance.
-template <int TRAV, bool COUNT, typename T, bool SPILL>
+template <int TRAV, bool COUNT, class ST, bool SPILL>
 RT_HD bool path_step(const DevScene &sc, const SceneView &vw, const DevCamera &cam, PathState &ps,
-                     const TravStack<T> &st, unsigned &n_rays, Cnt<COUNT> &cn) {
+                     const ST &st, unsigned &n_rays, Cnt<COUNT> &cn) {
     if (ps.depth <= 0) return false; // camera.h:141
     n_rays++;
     TraceHit h;
     if constexpr (TRAV == TRAV_LINEAR)
         h = trace_linear<COUNT>(sc, vw, ps.ray, 0.001f, RT_INF, cn);
     else
-        h = trace_bvh<COUNT, T, SPILL>(sc, vw, ps.ray, 0.001f, RT_INF, st, cn);
+        h = trace_bvh<COUNT, ST, SPILL>(sc, vw, ps.ray, 0.001f, RT_INF, st, cn);
     return path_after_trace<COUNT>(sc, vw, cam, ps, h, cn);
 }
 

@@ -160,26 +160,85 @@ struct Wide {
     int levels = 0;        // inner levels (a tree that is one node has 1)
 };
 
-// Every wide node starts from a binary node's two children and keeps replacing the inner child
-// with the largest box by that child's own two children until it has four (or only leaves).
+// Which binary nodes become wide nodes is chosen to minimise the surface-area cost of the wide
+// tree (sum over its nodes of the area of their box: the expected number of node visits of a
+// random ray), by dynamic programming over the binary tree: cost[n][i] is the cheapest way to
+// hang subtree n into i child slots of a wide node, either as one child that is a wide node
+// itself (its own four slots shared out between n's two children) or, for i > 1, by sharing the
+// i slots out between n's children directly.
 inline Wide collapse_to_wide(const std::vector<f4> &bin) {
     Wide w;
     const int n2 = (int)(bin.size() / 4);
     if (n2 == 0) return w;
-    w.nodes.reserve((size_t)(n2 / 2 + 1) * 8);
-    struct Child {
-        float box[6]; // centre, half extent
-        int ref;      // reference in the binary tree
-    };
-    auto children_of = [&](int node, Child out[2]) {
-        const float *q = reinterpret_cast<const float *>(&bin[(size_t)node * 4]);
-        for (int k = 0; k < 2; k++) {
-            memcpy(out[k].box, q + 6 * k, 6 * sizeof(float));
-            out[k].ref = __builtin_bit_cast(int, q[12 + k]);
+    auto words = [&](int node) { return reinterpret_cast<const float *>(&bin[(size_t)node * 4]); };
+    auto child_ref = [&](int node, int k) { return __builtin_bit_cast(int, words(node)[12 + k]); };
+    // post-order of the binary nodes, and the area of each one's box (kept in its parent)
+    std::vector<int> order;
+    std::vector<float> area((size_t)n2, 0.0f);
+    order.reserve(n2);
+    {
+        std::vector<int> stack{0};
+        while (!stack.empty()) {
+            int n = stack.back();
+            stack.pop_back();
+            order.push_back(n);
+            for (int k = 0; k < 2; k++) {
+                int r = child_ref(n, k);
+                if (r >= 0) {
+                    area[r] = half_area(words(n) + 6 * k + 3);
+                    stack.push_back(r);
+                }
+            }
         }
+        const float *q = words(0); // the root's own box: the union of its children's
+        float h[3];
+        for (int a = 0; a < 3; a++) {
+            float lo = std::min(q[a] - q[3 + a], q[6 + a] - q[9 + a]), hi = std::max(q[a] + q[3 + a], q[6 + a] + q[9 + a]);
+            h[a] = 0.5f * (hi - lo);
+        }
+        area[0] = half_area(h);
+    }
+    struct Cost {
+        float c[5];       // c[i], i = 1..4 (a leaf costs nothing wherever it hangs)
+        unsigned char split[5]; // slots given to the left child when i slots are shared out; 0: c[i] = c[i-1]
+        unsigned char node_split;  // the same for the node's own four slots
     };
+    std::vector<Cost> cost((size_t)n2);
+    auto sub = [&](int ref, int i) { return ref >= 0 ? cost[ref].c[i] : 0.0f; };
+    for (size_t t = order.size(); t-- > 0;) {
+        const int n = order[t];
+        const int l = child_ref(n, 0), r = child_ref(n, 1);
+        Cost &c = cost[n];
+        float best = INFINITY;
+        for (int k = 1; k <= 3; k++) {
+            float v = sub(l, k) + sub(r, 4 - k);
+            if (v < best) {
+                best = v;
+                c.node_split = (unsigned char)k;
+            }
+        }
+        c.c[1] = area[n] + best;
+        c.split[1] = 0;
+        for (int i = 2; i <= 4; i++) {
+            c.c[i] = c.c[i - 1];
+            c.split[i] = 0;
+            for (int k = 1; k < i; k++) {
+                float v = sub(l, k) + sub(r, i - k);
+                if (v < c.c[i]) {
+                    c.c[i] = v;
+                    c.split[i] = (unsigned char)k;
+                }
+            }
+        }
+    }
+    // top-down: every wide node gathers its children in the binary tree's left-to-right order
+    w.nodes.reserve((size_t)(n2 / 2 + 1) * 8);
     struct Item {
         int bin_node, wide_node, level;
+    };
+    struct Child {
+        float box[6];
+        int ref;
     };
     std::vector<Item> todo;
     auto new_node = [&]() {
@@ -192,23 +251,32 @@ inline Wide collapse_to_wide(const std::vector<f4> &bin) {
         todo.pop_back();
         w.levels = std::max(w.levels, it.level);
         Child c[4];
-        int n = 2;
-        children_of(it.bin_node, c);
-        while (n < 4) {
-            int pick = -1;
-            float best = -1.0f;
-            for (int k = 0; k < n; k++)
-                if (c[k].ref >= 0 && half_area(c[k].box + 3) > best) {
-                    best = half_area(c[k].box + 3);
-                    pick = k;
-                }
-            if (pick < 0) break;
-            Child two[2];
-            children_of(c[pick].ref, two);
-            c[pick] = two[0]; // the left child keeps the place: the order of the leaves is the binary tree's
-            for (int k = n; k > pick + 1; k--) c[k] = c[k - 1];
-            c[pick + 1] = two[1];
-            n++;
+        int n = 0;
+        // shares `slots` slots out below binary node `node`; `box` is the node's own box
+        struct Frame {
+            int node, k, slots;
+        };
+        std::vector<Frame> fr;
+        const int ks = cost[it.bin_node].node_split;
+        fr.push_back({it.bin_node, 1, 4 - ks});
+        fr.push_back({it.bin_node, 0, ks});
+        while (!fr.empty()) {
+            const Frame f = fr.back();
+            fr.pop_back();
+            const float *q = words(f.node);
+            const int ref = child_ref(f.node, f.k);
+            int slots = f.slots;
+            if (ref >= 0)
+                while (slots > 1 && cost[ref].split[slots] == 0) slots--; // as good with fewer slots
+            if (ref < 0 || slots == 1) { // a leaf, or a subtree that becomes a wide node of its own
+                memcpy(c[n].box, q + 6 * f.k, 6 * sizeof(float));
+                c[n].ref = ref;
+                n++;
+            } else {
+                const int kl = cost[ref].split[slots];
+                fr.push_back({ref, 1, slots - kl});
+                fr.push_back({ref, 0, kl});
+            }
         }
         int refs[4] = {0, 0, 0, 0};
         float boxes[24];

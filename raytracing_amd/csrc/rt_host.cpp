@@ -249,7 +249,7 @@ LaunchGeom choose_geom(rt_scene *s, uint32_t flags) {
     if (!(flags & RT_SCENE_FORCE_GLOBAL) && short_ok) {
         for (bpc = bpc_target; bpc >= 1 && !lg.lds_scene; bpc--) {
             size_t budget = (size_t)kMaxLdsBytes / bpc;
-            size_t stack = (size_t)cap * block * sizeof(short);
+            size_t stack = (size_t)cap * RT_MEGA_MAX_THREADS * sizeof(short); // rows of the full workgroup size
             if (all_bytes + stack <= budget) {
                 lg.lds_scene = true;
                 lg.lds_records = 1;
@@ -286,7 +286,7 @@ LaunchGeom choose_geom(rt_scene *s, uint32_t flags) {
         while ((1ll << bits) < std::max<long long>(dv.n_nodes, 2ll * dv.n_slots)) bits++;
         dv.ref_bits = std::max(16, std::min(32, bits + 1));
         lg.stack_lds_entries = bvh ? std::max(4, std::min(cap, env_int("RT_AMD_LDS_STACK", 24))) : 0;
-        size_t stack = (size_t)lg.stack_lds_entries * block * sizeof(int);
+        size_t stack = (size_t)lg.stack_lds_entries * RT_MEGA_MAX_THREADS * sizeof(int);
         bpc = std::max(1, std::min(bpc_target, (int)(kMaxLdsBytes / std::max<size_t>(stack + ring_bytes, 1))));
         size_t budget = (size_t)kMaxLdsBytes / bpc;
         lg.ring = ring_bytes && stack + ring_bytes <= budget;
@@ -492,7 +492,7 @@ static int impl_rt_scene_create(const rt_scene_desc *d, int device, uint32_t fla
 
     s->geom = choose_geom(s, flags);
     if (s->geom.stack_cap > s->geom.stack_lds_entries) {
-        const size_t bytes = (size_t)(s->geom.stack_cap - s->geom.stack_lds_entries) * s->geom.grid * s->geom.block * sizeof(int);
+        const size_t bytes = (size_t)(s->geom.stack_cap - s->geom.stack_lds_entries) * s->geom.grid * RT_MEGA_MAX_THREADS * sizeof(int);
         for (int k = 0; k < 3; k++) {
             void *p = nullptr;
             if (hipMalloc(&p, bytes) != hipSuccess) {

@@ -33,7 +33,7 @@ using namespace rtc;
 #endif
 
 #ifndef RT_INNER_UNROLL
-#define RT_INNER_UNROLL 4
+#define RT_INNER_UNROLL 2
 #endif
 
 namespace {
@@ -55,9 +55,9 @@ struct SchedStats { // wave-level schedule statistics (instrumented variants onl
 // together once leaf_min lanes hold one, blocked_min lanes have run into a second leaf, or no
 // lane has an inner node left.  Lanes whose traversal ends leave in ST_READY with the closest
 // hit in tv.best_t / tv.best_slot.
-template <bool LDS_SCENE, bool COUNT, typename T, bool SPILL>
+template <bool LDS_SCENE, bool COUNT, class ST, bool SPILL>
 __device__ __forceinline__ void wave_traverse(int &state, Trav &tv, int &pend, const Ray &ray, const DevScene &sc,
-                                              const SceneView &vw, const TravStack<T> &st, float tmin, int min_ready,
+                                              const SceneView &vw, const ST &st, float tmin, int min_ready,
                                               int leaf_min, int blocked_min, bool idle_counts, Cnt<COUNT> &cn,
                                               SchedStats &ss) {
     long long c_mark = 0;
@@ -78,10 +78,10 @@ __device__ __forceinline__ void wave_traverse(int &state, Trav &tv, int &pend, c
 #pragma unroll
         for (int k = 0; k < RT_INNER_UNROLL; k++) {
             if (trav && tv.ref >= 0)
-                trav_inner<COUNT, T, !LDS_SCENE, SPILL>(tv, vw.nodes, tmin, st, sc.ref_bits, cn, vw.top, vw.n_top);
+                trav_inner<COUNT, ST, !LDS_SCENE, SPILL>(tv, vw.nodes, tmin, st, sc.ref_bits, cn, vw.top, vw.n_top);
             if (trav && tv.ref < 0 && tv.ref != RT_TRAV_DONE && pend == 0) {
                 pend = tv.ref;
-                trav_pop<T, SPILL>(tv, st, sc.ref_bits);
+                trav_pop<ST, SPILL>(tv, st, sc.ref_bits);
             }
         }
         if constexpr (COUNT) {
@@ -105,7 +105,7 @@ __device__ __forceinline__ void wave_traverse(int &state, Trav &tv, int &pend, c
                     pend = 0;
                     if (blocked) {
                         pend = tv.ref;
-                        trav_pop<T, SPILL>(tv, st, sc.ref_bits);
+                        trav_pop<ST, SPILL>(tv, st, sc.ref_bits);
                     }
                 }
             }
@@ -130,7 +130,8 @@ render_mega(DevScene sc, DevCamera cam, RenderParams rp) {
     else __syncthreads();
     using StackT = typename std::conditional<LDS_SCENE, short, int>::type;
     constexpr bool SPILL = !LDS_SCENE;
-    const TravStack<StackT> st = lane_stack<StackT, SPILL>(free_lds, sc, rp.stack_lds_entries, rp.stack_spill);
+    typedef TravStack<StackT, RT_MEGA_MAX_THREADS> Stack;
+    const Stack st = lane_stack<StackT, SPILL, RT_MEGA_MAX_THREADS>(free_lds, sc, rp.stack_lds_entries, rp.stack_spill);
     // RING: the camera rays of the wave's current unit (see render_mega_bvh)
     f4 *ring = RING ? smem + rp.ring_f4 + (size_t)(threadIdx.x >> 6) * RT_RING_F4_PER_WAVE : nullptr;
 
@@ -217,7 +218,7 @@ render_mega(DevScene sc, DevCamera cam, RenderParams rp) {
                     if constexpr (TRAV == TRAV_LINEAR)
                         h = trace_linear<COUNT>(sc, vw, ps.ray, 0.001f, RT_INF, cn);
                     else
-                        h = trace_bvh<COUNT, StackT, SPILL>(sc, vw, ps.ray, 0.001f, RT_INF, st, cn);
+                        h = trace_bvh<COUNT, Stack, SPILL>(sc, vw, ps.ray, 0.001f, RT_INF, st, cn);
                 }
                 long long c1 = clock64();
                 if (go) cont = path_after_trace<COUNT>(sc, vw, cam, ps, h, cn);
@@ -229,7 +230,7 @@ render_mega(DevScene sc, DevCamera cam, RenderParams rp) {
                     w_cycles[4] += __popcll(__ballot(true));
                 }
             } else {
-                cont = path_step<TRAV, COUNT, StackT, SPILL>(sc, vw, cam, ps, st, n_rays, cn);
+                cont = path_step<TRAV, COUNT, Stack, SPILL>(sc, vw, cam, ps, st, n_rays, cn);
             }
             if (!cont) {
                 write_record(rp, sample, pixel, ps.L, n_rays);
@@ -274,7 +275,8 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
         __syncthreads();
     }
     constexpr bool SPILL = !LDS_SCENE;
-    const TravStack<StackT> st = lane_stack<StackT, SPILL>(free_lds, sc, rp.stack_lds_entries, rp.stack_spill);
+    typedef TravStack<StackT, RT_MEGA_MAX_THREADS> Stack;
+    const Stack st = lane_stack<StackT, SPILL, RT_MEGA_MAX_THREADS>(free_lds, sc, rp.stack_lds_entries, rp.stack_spill);
     // RING: the camera rays of the wave's current unit, structure of arrays over its 64 paths
     f4 *ring = RING ? smem + rp.ring_f4 + (size_t)(threadIdx.x >> 6) * RT_RING_F4_PER_WAVE : nullptr;
 
@@ -496,7 +498,7 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
             continue;
         }
         // ---- traversal steps until enough lanes wait for shading ------------------------------
-        wave_traverse<LDS_SCENE, COUNT, StackT, SPILL>(state, tv, pend, ps.ray, sc, vw, st, 0.001f, min_ready, leaf_min,
+        wave_traverse<LDS_SCENE, COUNT, Stack, SPILL>(state, tv, pend, ps.ray, sc, vw, st, 0.001f, min_ready, leaf_min,
                                                        blocked_min, !pool_dry, cn, ss);
     }
     };
@@ -621,7 +623,8 @@ template <int TRAV>
 __global__ void __launch_bounds__(RT_TRACE_THREADS)
 trace_batch(DevScene sc, const rt_ray *rays, long long n_rays, float tmin, float tmax, rt_hit *hits) {
     extern __shared__ f4 smem[];
-    const TravStack<int> st = lane_stack<int, false>(smem, sc, sc.stack_cap, nullptr);
+    typedef TravStack<int, RT_TRACE_THREADS> Stack;
+    const Stack st = lane_stack<int, false, RT_TRACE_THREADS>(smem, sc, sc.stack_cap, nullptr);
     const SceneView vw = global_view(sc);
     Cnt<false> cn;
     for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < n_rays;
@@ -635,7 +638,7 @@ trace_batch(DevScene sc, const rt_ray *rays, long long n_rays, float tmin, float
         if constexpr (TRAV == TRAV_LINEAR)
             h = trace_linear<false>(sc, vw, r, tmin, tmax, cn);
         else
-            h = trace_bvh<false, int, false>(sc, vw, r, tmin, tmax, st, cn);
+            h = trace_bvh<false, Stack, false>(sc, vw, r, tmin, tmax, st, cn);
         hits[k] = make_hit_record(sc, vw, r, h);
     }
 }
@@ -661,7 +664,8 @@ trace_sched(DevScene sc, RenderParams rp, const rt_ray *rays, long long n_rays, 
         __syncthreads();
     }
     constexpr bool SPILL = !LDS_SCENE;
-    const TravStack<StackT> st = lane_stack<StackT, SPILL>(free_lds, sc, rp.stack_lds_entries, rp.stack_spill);
+    typedef TravStack<StackT, RT_MEGA_MAX_THREADS> Stack;
+    const Stack st = lane_stack<StackT, SPILL, RT_MEGA_MAX_THREADS>(free_lds, sc, rp.stack_lds_entries, rp.stack_spill);
     const int lane = threadIdx.x & 63;
     const unsigned long long lane_mask_lt = (1ull << lane) - 1ull;
     const unsigned long long n_batches = (unsigned long long)((n_rays + 63) / 64);
@@ -719,7 +723,7 @@ trace_sched(DevScene sc, RenderParams rp, const rt_ray *rays, long long n_rays, 
             if (exhausted) break;
             continue;
         }
-        wave_traverse<LDS_SCENE, false, StackT, SPILL>(state, tv, pend, ray, sc, vw, st, tmin, rp.min_ready, rp.leaf_min,
+        wave_traverse<LDS_SCENE, false, Stack, SPILL>(state, tv, pend, ray, sc, vw, st, tmin, rp.min_ready, rp.leaf_min,
                                                        rp.blocked_min, !exhausted, cn, ss);
     }
 }

@@ -49,15 +49,16 @@ __device__ __forceinline__ f4 *stage_scene(const DevScene &sc, f4 *smem, SceneVi
 
 // This lane's traversal stack: a column of the workgroup's [entry][lane] array that starts at
 // `lds_words`, and (SPILL) a column of the same shape in global memory for the entries beyond.
-template <typename T, bool SPILL>
-__device__ __forceinline__ TravStack<T> lane_stack(f4 *lds_words, const DevScene &sc, int lds_entries, int *spill) {
-    TravStack<T> st;
+// STRIDE: lanes per entry row, whatever the workgroup's size (0: the workgroup's size).
+template <typename T, bool SPILL, int STRIDE>
+__device__ __forceinline__ TravStack<T, STRIDE> lane_stack(f4 *lds_words, const DevScene &sc, int lds_entries, int *spill) {
+    TravStack<T, STRIDE> st;
     st.lds = reinterpret_cast<T *>(lds_words) + threadIdx.x;
-    st.stride = (int)blockDim.x;
-    st.lds_end = lds_entries * (int)blockDim.x;
+    st.rt_stride = (int)blockDim.x;
+    st.lds_end = lds_entries * st.stride();
     st.spill = nullptr;
     if constexpr (SPILL)
-        st.spill = spill + (size_t)blockIdx.x * (size_t)(sc.stack_cap - lds_entries) * blockDim.x + threadIdx.x;
+        st.spill = spill + (size_t)blockIdx.x * (size_t)(sc.stack_cap - lds_entries) * st.stride() + threadIdx.x;
     return st;
 }
 

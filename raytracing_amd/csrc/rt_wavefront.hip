@@ -131,7 +131,8 @@ wf_trace(DevScene sc, WfBuffers wf, const int *q_trace_cur, int stack_lds_entrie
     if constexpr (LDS_SCENE) free_lds = stage_scene(sc, smem, vw);
     using StackT = typename std::conditional<LDS_SCENE, short, int>::type;
     constexpr bool SPILL = !LDS_SCENE;
-    const TravStack<StackT> stk = lane_stack<StackT, SPILL>(free_lds, sc, stack_lds_entries, stack_spill);
+    typedef TravStack<StackT, RT_MEGA_MAX_THREADS> Stack;
+    const Stack stk = lane_stack<StackT, SPILL, RT_MEGA_MAX_THREADS>(free_lds, sc, stack_lds_entries, stack_spill);
     Cnt<false> cn;
     const unsigned stride = gridDim.x * blockDim.x;
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -146,7 +147,7 @@ wf_trace(DevScene sc, WfBuffers wf, const int *q_trace_cur, int stack_lds_entrie
         if constexpr (TRAV == TRAV_LINEAR)
             h = trace_linear<false>(sc, vw, r, 0.001f, RT_INF, cn);
         else
-            h = trace_bvh<false, StackT, SPILL>(sc, vw, r, 0.001f, RT_INF, stk, cn);
+            h = trace_bvh<false, Stack, SPILL>(sc, vw, r, 0.001f, RT_INF, stk, cn);
         // the first 8 bytes of the auxiliary record: {t, slot}
         *reinterpret_cast<float2 *>(&wf.aux[slot]) = float2{h.t, __builtin_bit_cast(float, h.slot)};
         wf.key[i] = h.slot < 0 ? (int)Q_MISS : RT_KIND_MAT(vw.rec_i[h.slot].x);

@@ -81,11 +81,11 @@ struct SimStacks {
     explicit SimStacks(const DevScene &sc) : a(sc.stack_cap + 8), b(sc.stack_cap + 8), h(sc.stack_cap + 8) {
         st32.lds = a.data();
         st32.spill = b.data();
-        st32.stride = 1;
+        st32.rt_stride = 1;
         st32.lds_end = g_stack_mode == 2 ? 4 : sc.stack_cap + 8;
         st16.lds = h.data();
         st16.spill = nullptr;
-        st16.stride = 1;
+        st16.rt_stride = 1;
         st16.lds_end = sc.stack_cap + 8;
     }
 };
@@ -93,10 +93,10 @@ template <bool COUNT> TraceHit sim_trace_bvh(DevScene sc, const SceneView &vw, c
                                              SimStacks &k, Cnt<COUNT> &cn) {
     if (g_stack_mode == 1 && sc.n_nodes < 32768 && sc.n_slots < 16384) {
         sc.ref_bits = 16;
-        return trace_bvh<COUNT, short, false>(sc, vw, r, tmin, tmax, k.st16, cn);
+        return trace_bvh<COUNT, TravStack<short>, false>(sc, vw, r, tmin, tmax, k.st16, cn);
     }
-    if (g_stack_mode == 2) return trace_bvh<COUNT, int, true>(sc, vw, r, tmin, tmax, k.st32, cn);
-    return trace_bvh<COUNT, int, false>(sc, vw, r, tmin, tmax, k.st32, cn);
+    if (g_stack_mode == 2) return trace_bvh<COUNT, TravStack<int>, true>(sc, vw, r, tmin, tmax, k.st32, cn);
+    return trace_bvh<COUNT, TravStack<int>, false>(sc, vw, r, tmin, tmax, k.st32, cn);
 }
 } // namespace
 } // extern "C++"
