@@ -1,15 +1,23 @@
 #!/usr/bin/env python3
 """Benchmark of the path-tracing hot path on MI355X.
 
-One step = one pass of the hot path over one batch of synthetic input: every rank renders
-`--spp` samples per pixel of the workload scene into its own fp32 accumulation image in HBM
-(rt_render_device through the C ABI); with more than one rank the images are combined by one
-RCCL reduce (sum, fp32) to rank 0.  Per-GPU work is fixed as N grows (weak scaling): rank r
-renders global samples [r*spp, (r+1)*spp).
+One step = one pass of the hot path over one batch of synthetic input: every rank renders its
+share of the step's samples per pixel of the workload scene into an fp32 accumulation image in
+HBM (rt_render_device through the C ABI); with more than one rank the images are combined by
+one RCCL reduce (sum, fp32) to rank 0, issued asynchronously so that it overlaps the next
+step's render.  --scaling weak (default): every rank renders --spp samples per step (rank r the
+global samples [r*spp, (r+1)*spp)); --scaling strong: --spp is the step's total, split across
+the ranks (spp_split.sample_range).
+
+`python bench.py --gpus N` without a launcher starts the N ranks itself (fresh processes, before
+anything in the parent touches the GPU) and fails if fewer than N devices are visible; under
+torch.distributed.run (RANK / WORLD_SIZE in the environment) it is one of the ranks.
 
 Prints ONE JSON line (rank 0).  `value` is whole-job Mpaths/s with the scene already resident
-in HBM; `roofline` prices the render kernel against the FP32 vector peak; `cpu_baseline` is
-the reference renderer (or the oracle port) timed on this box's host cores on a bounded sample.
+in HBM, the median of --repeats timed regions of --steps steps each (`ms_per_step` likewise;
+`repeat_values` lists them all); `roofline` prices the render kernel against the FP32 vector
+peak; `cpu_baseline` is the reference renderer timed on this box's host cores on a bounded
+sample; `configs` (one GPU only) holds the same measurements for the other workloads.
 
 Consecutive steps overlap on the GPU (the library alternates two internal streams, so the
 long-path tail of one launch runs beside the start of the next): inside the timed region a
@@ -19,8 +27,10 @@ same launch running alone, measured with HIP events over `--iso-steps` further s
 timed region (RT_RENDER_NO_OVERLAP); `--serial` runs the timed region itself that way.
 """
 import argparse
+import hashlib
 import json
 import os
+import statistics
 import subprocess
 import sys
 import time
@@ -28,10 +38,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-
 GOLD = os.path.join(ROOT, "tests", "golden")
 PEAK_FP32_VALU_TFLOPS = 157.3  # 256 CU x 128 lanes x 2 (FMA) x 2.4 GHz
+PEAK_HBM_GBS = 8000.0
 
 # Nominal fp32 operation weights of the reference algorithm's steps (1 per add / mul / compare /
 # min / max, 1 per divide / sqrt / transcendental): the "algorithmic flops" of one launch are
@@ -70,174 +79,348 @@ def measured_traffic(scene, width, height, spp, key="traffic_bytes_per_launch"):
     return best
 
 
-def cpu_baseline(scene, budget_paths):
-    """Times the reference renderer (oracle/_ref/rt_ref, built from the unmodified reference in
-    the authoring container) on one host core; falls back to the oracle port if it is absent."""
+def _sha16(path):
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline(scene, budget_paths, arrays=None, cam=None, port_too=True):
+    """Times the reference renderer (oracle/_ref/rt_ref: the unmodified reference, compiled by
+    __graft_entry__.build() where its sources exist and carried along as a binary) on one host
+    core, and the oracle port beside it on a smaller sample; says which binary was timed.
+    Scenes the reference does not have (synth1m) are timed with the port only."""
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "rt_ref")
     from raytracing_amd import abi
-    cam, _ = abi.load_camera_file(os.path.join(GOLD, scene + ".cam"))
+    if cam is None:
+        cam, _ = abi.load_camera_file(os.path.join(GOLD, scene + ".cam"))
     w, h = cam.image_width, cam.image_height()
     spp = max(1, int(round(budget_paths / (w * h))))
-    if os.path.exists(ref_bin):
+    out = None
+    if arrays is None and os.path.exists(ref_bin):
         try:
             env = dict(os.environ, RTW_IMAGES=os.path.join(GOLD, "images"))  # earth's texture file
-            out = subprocess.run([ref_bin, "render", scene, str(spp), "0", "0", "0", "-"], check=True,
+            res = subprocess.run([ref_bin, "render", scene, str(spp), "0", "0", "0", "-"], check=True,
                                  capture_output=True, cwd="/tmp", timeout=600, env=env)
-            m = json.loads(out.stdout.decode().strip().splitlines()[-1])
-            return {"value": m["mpaths_per_s"], "unit": "Mpaths/s", "cores": 1, "kind": "reference",
-                    "mrays_per_s": m["mrays_per_s"],
-                    "sample": f"{scene} {w}x{h} at {spp} spp, depth {cam.max_depth} "
-                              f"({m['paths']} paths, {m['seconds']:.1f} s, unmodified reference, 1 thread)"}
+            m = json.loads(res.stdout.decode().strip().splitlines()[-1])
+            out = {"value": m["mpaths_per_s"], "unit": "Mpaths/s", "cores": 1, "kind": "reference",
+                   "mrays_per_s": m["mrays_per_s"], "binary": "oracle/_ref/rt_ref", "binary_sha256_16": _sha16(ref_bin),
+                   "sample": f"{scene} {w}x{h} at {spp} spp, depth {cam.max_depth} "
+                             f"({m['paths']} paths, {m['seconds']:.1f} s, unmodified reference, 1 thread)"}
         except Exception as e:  # noqa: BLE001
             print(f"[bench] reference binary failed ({e}); timing the oracle port", file=sys.stderr)
+    if out is not None and not port_too:
+        return out
     from tests import oracle_lib as O
-    arrays = abi.SceneArrays.load(os.path.join(GOLD, scene + ".rtscene"))
+    if arrays is None:
+        arrays = abi.SceneArrays.load(os.path.join(GOLD, scene + ".rtscene"))
     osc = O.OracleScene(arrays)
-    _, st = osc.render(cam, spp, sampler=O.SAMPLER_REF, trace_mode=O.TRACE_REFERENCE)
-    return {"value": st.paths / st.seconds * 1e-6, "unit": "Mpaths/s", "cores": 1, "kind": "port",
-            "mrays_per_s": st.rays / st.seconds * 1e-6,
-            "sample": f"{scene} {w}x{h} at {spp} spp, depth {cam.max_depth} "
+    pspp = spp if out is None else max(1, spp // 4)
+    _, st = osc.render(cam, pspp, sampler=O.SAMPLER_REF, trace_mode=O.TRACE_REFERENCE)
+    port = {"value": st.paths / st.seconds * 1e-6, "unit": "Mpaths/s", "cores": 1, "kind": "port",
+            "mrays_per_s": st.rays / st.seconds * 1e-6, "binary": "oracle/liboracle.so",
+            "sample": f"{scene} {w}x{h} at {pspp} spp, depth {cam.max_depth} "
                       f"({st.paths} paths, {st.seconds:.1f} s, oracle port, 1 thread)"}
+    if out is None:
+        return port
+    out["port"] = {k: port[k] for k in ("value", "mrays_per_s", "sample")}
+    return out
+
+
+class Workload:
+    """A scene resident on this rank's GPU and what it takes to step it."""
+
+    def __init__(self, name, arrays, cam, device_index, serial):
+        import torch
+
+        from raytracing_amd import binding, spp_split
+        self.torch, self.name, self.cam = torch, name, cam
+        self.scene = binding.Scene(arrays, device=device_index)
+        self.info = self.scene.info()
+        self.H, self.W = cam.image_height(), cam.image_width
+        self.dev = torch.device("cuda", device_index)
+        self.render = spp_split.gpu_render_fn(self.scene, cam, seed=0, overlap=not serial)
+        self.render_alone = spp_split.gpu_render_fn(self.scene, cam, seed=0, overlap=False)
+        self.pipe = spp_split.SplitPipeline(self.render, (self.H, self.W, 3), self.dev)
+        self.pipe_alone = spp_split.SplitPipeline(self.render_alone, (self.H, self.W, 3), self.dev)
+
+    def close(self):
+        self.scene.close()
+
+    def measure(self, begin, count, steps, warmup, repeats, iso_steps, serial, use_dist):
+        """Times `repeats` regions of `steps` steps (this rank renders samples [begin, begin +
+        count) per step).  Returns per-rank results; the caller combines ranks."""
+        import torch.distributed as dist
+        torch = self.torch
+        scratch = torch.zeros((self.H, self.W, 3), dtype=torch.float32, device=self.dev)
+        st = self.scene.render_device(self.cam, count, scratch.data_ptr(), stream=torch.cuda.current_stream().cuda_stream,
+                                      sample_begin=begin, seed=0, counters=True)
+        del scratch
+
+        def step(pipe=self.pipe):
+            pipe.frame(0, begin_count=(begin, count))
+
+        for _ in range(warmup):
+            step()
+        self.pipe.finish()
+        elapsed, kernel_ms, n_launches = [], 0.0, 0
+        for _ in range(repeats):
+            torch.cuda.synchronize()
+            if use_dist:
+                dist.barrier()
+            self.scene.profile_begin()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            self.pipe.finish()
+            torch.cuda.synchronize()
+            if use_dist:
+                dist.barrier()
+            elapsed.append(time.perf_counter() - t0)
+            ms, n = self.scene.profile_end()
+            kernel_ms += ms
+            n_launches += n
+        iso_ms, iso_launches = kernel_ms, n_launches
+        if not serial and iso_steps > 0:
+            torch.cuda.synchronize()
+            self.scene.profile_begin()
+            for _ in range(iso_steps):
+                step(self.pipe_alone)
+            self.pipe_alone.finish()
+            torch.cuda.synchronize()
+            iso_ms, iso_launches = self.scene.profile_end()
+        return {"stats": st, "elapsed": elapsed, "kernel_ms": kernel_ms, "n_launches": n_launches,
+                "iso_ms": iso_ms, "iso_launches": iso_launches}
+
+    def kernel_name(self):
+        return "render_mega_bvh" if self.info.n_nodes else "render_mega"
+
+    def describe(self, spp_text):
+        i = self.info
+        tree = (f"{i.n_nodes} nodes of a 4-wide BVH, {i.bvh_depth} levels, "
+                f"{'LDS' if i.lds_resident else 'HBM'}-resident geometry") if i.n_nodes else "scanned, no tree"
+        return f"{self.name} {self.W}x{self.H}, {spp_text}, max_depth {self.cam.max_depth}, {i.n_prims} primitives ({tree})"
+
+
+def roofline_of(wl, m, steps_total, spp_per_launch_hint):
+    st = m["stats"]
+    alg = algorithmic_flops(st)
+    avg_kernel_s = m["iso_ms"] / max(m["iso_launches"], 1) * 1e-3
+    launches_per_step = max(m["n_launches"], 1) / steps_total
+    achieved = alg / launches_per_step / avg_kernel_s / 1e12 if avg_kernel_s > 0 else 0.0
+    traffic = measured_traffic(wl.name, wl.W, wl.H, spp_per_launch_hint)
+    return {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
+            "pmc": measured_traffic(wl.name, wl.W, wl.H, spp_per_launch_hint, key="pmc"),
+            "hbm_gb_per_s": (traffic / avg_kernel_s * 1e-9) if traffic and avg_kernel_s > 0 else None,
+            "hbm_frac_of_peak": (traffic / avg_kernel_s * 1e-9 / PEAK_HBM_GBS) if traffic and avg_kernel_s > 0 else None,
+            "kernel": wl.kernel_name(), "kernel_ms_avg": avg_kernel_s * 1e3,
+            "kernel_ms_overlapped_avg": m["kernel_ms"] / max(m["n_launches"], 1),
+            "launches": m["n_launches"], "isolated_launches": m["iso_launches"],
+            "launches_per_step": launches_per_step,
+            "algorithmic_flops_per_launch": alg / launches_per_step,
+            "counts_per_step": {"paths": st.paths, "rays": st.rays, "box_tests": st.box_tests,
+                                "sphere_tests": st.sphere_tests, "sphere_hits": st.sphere_hits,
+                                "quad_tests": st.quad_tests, "shades": list(st.shades),
+                                "noise_evals": st.noise_evals, "image_evals": st.image_evals}}
+
+
+def load_workload(name, width=0):
+    """(arrays, cam) of a golden scene, or of synth1m from the scene program (None if it is absent)."""
+    from raytracing_amd import abi
+    if name == "synth1m":
+        prog = os.path.join(ROOT, "examples", "bin", "rt_scenes")
+        if not os.path.exists(prog):
+            return None
+        out = "/tmp/bench_synth1m.rtscene"
+        subprocess.run([prog, "synth1m", "--half", "500", "--dump", out], check=True, capture_output=True)
+        arrays = abi.SceneArrays.load(out)
+        cam = abi.load_camera_file(out + ".cam")[0]
+    else:
+        arrays = abi.SceneArrays.load(os.path.join(GOLD, name + ".rtscene"))
+        cam, _ = abi.load_camera_file(os.path.join(GOLD, name + ".cam"))
+    if width:
+        cam.image_width = width
+    return arrays, cam
+
+
+# the other workloads BASELINE.json names, as one GPU runs them: (scene, spp per step, steps, CPU sample in paths)
+OTHER_CONFIGS = [
+    ("config2", "checkered_spheres", 100, 10, 4.5e6), ("config2", "perlin_spheres", 100, 10, 1.8e6),
+    ("config3", "earth", 100, 10, 9e6), ("config3", "quads", 100, 10, 6.4e6), ("config3", "simple_light", 100, 10, 3.6e6),
+    ("config4", "cornell_box", 2048, 1, 2.88e6),   # one GPU's share of 16 384 spp over 8
+    ("config5", "synth1m", 8, 2, 0.13e6),           # 3840x2160, 8 of the 1024 spp
+]
+
+
+def run_other_configs(args, dev_index):
+    out = {}
+    for cfg, name, spp, steps, cpu_paths in OTHER_CONFIGS:
+        loaded = load_workload(name)
+        if loaded is None:
+            out[name] = {"config": cfg, "skipped": "examples/bin/rt_scenes (the scene program) is not built"}
+            continue
+        arrays, cam = loaded
+        cam.samples_per_pixel = spp
+        wl = Workload(name, arrays, cam, dev_index, serial=False)
+        m = wl.measure(0, spp, steps, 1, 3, 2, False, False)
+        el = statistics.median(m["elapsed"])
+        st = m["stats"]
+        r = roofline_of(wl, m, steps * 3, spp)
+        entry = {"config": cfg, "workload": wl.describe(f"{spp} spp per step"), "steps": steps, "repeats": 3,
+                 "value": st.paths * steps / el * 1e-6, "unit": "Mpaths/s", "mrays_per_s": st.rays * steps / el * 1e-6,
+                 "rays_per_path": st.rays / max(st.paths, 1), "ms_per_step": el / steps * 1e3,
+                 "kernel": r["kernel"], "kernel_ms_alone": r["kernel_ms_avg"], "launches_per_step": r["launches_per_step"],
+                 "roofline": {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "hbm_gb_per_s",
+                                                "hbm_frac_of_peak", "algorithmic_flops_per_launch")}}
+        wl.close()
+        if not args.no_cpu_baseline:
+            if name == "synth1m":
+                small = cam.copy()
+                small.image_width = 480  # 480x270 at 1 spp: the exhaustive structures of the port take the time
+                entry["cpu_baseline"] = cpu_baseline(name, cpu_paths, arrays=arrays, cam=small)
+            else:
+                entry["cpu_baseline"] = cpu_baseline(name, cpu_paths, port_too=False)
+        out[name] = entry
+        print(f"[bench] {name}: {entry['value']:.0f} Mpaths/s, kernel alone {entry['kernel_ms_alone']:.3f} ms, "
+              f"frac {entry['roofline']['frac']:.4f}", file=sys.stderr)
+    return out
+
+
+def run_rank(args):
+    import torch
+    import torch.distributed as dist
+
+    from raytracing_amd import spp_split
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        print(f"[bench] --gpus {args.gpus} but {world} rank(s) were launched: refusing to report a mislabelled number",
+              file=sys.stderr)
+        return 2
+    # under torch.distributed.run the collectives run even with one rank (same code path as N > 1)
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    if local_rank >= torch.cuda.device_count():
+        print(f"[bench] rank {rank}: device {local_rank} does not exist ({torch.cuda.device_count()} visible)", file=sys.stderr)
+        return 2
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    strong = args.scaling == "strong"
+    scene_name = args.scene or ("cornell_box" if strong else "bouncing_spheres")
+    spp = args.spp or (16384 if strong else 100)
+    steps = args.steps if args.steps is not None else (2 if strong else 200)
+    warmup = args.warmup if args.warmup is not None else (1 if strong else 10)
+    arrays, cam = load_workload(scene_name, args.width)
+    if strong:
+        begin, count = spp_split.sample_range(spp, rank, world)
+        cam.samples_per_pixel = spp
+    else:
+        begin, count = rank * spp, spp
+        cam.samples_per_pixel = spp * world
+    wl = Workload(scene_name, arrays, cam, local_rank, args.serial)
+    m = wl.measure(begin, count, steps, warmup, args.repeats, args.iso_steps, args.serial, use_dist)
+    st = m["stats"]
+
+    elapsed = m["elapsed"]
+    if use_dist:
+        t = torch.tensor(elapsed, dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)  # every region: the slowest rank's time
+        elapsed = [float(x) for x in t.tolist()]
+        cnt = torch.tensor([st.paths, st.rays, 1], dtype=torch.float64, device=dev)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        total_paths, total_rays, joined = float(cnt[0].item()), float(cnt[1].item()), int(round(float(cnt[2].item())))
+    else:
+        total_paths, total_rays, joined = float(st.paths), float(st.rays), 1
+    if joined != args.gpus:
+        print(f"[bench] {joined} rank(s) joined the collective, --gpus {args.gpus}", file=sys.stderr)
+        return 2
+
+    if rank == 0:
+        values = [total_paths * steps / e * 1e-6 for e in elapsed]
+        med = statistics.median(elapsed)
+        spp_text = (f"{spp} spp per step split over {world} GPU(s)" if strong else f"{spp} spp per GPU per step")
+        out = {
+            "metric": "Mpaths/s",
+            "value": total_paths * steps / med * 1e-6,
+            "unit": "Mpaths/s",
+            "n_gpus": joined,
+            "steps": steps,
+            "warmup": warmup,
+            "ms_per_step": med / steps * 1e3,
+            "higher_is_better": True,
+            "scaling": args.scaling,
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "repeats": args.repeats,
+            "repeat_values": values,
+            "repeat_spread": (max(values) - min(values)) / statistics.median(values) if values else 0.0,
+            "mrays_per_s": total_rays * steps / med * 1e-6,
+            "rays_per_path": total_rays / total_paths,
+            "config": {"workload": wl.describe(spp_text), "scene": scene_name, "width": wl.W, "height": wl.H,
+                       "spp_per_gpu_per_step": count, "max_depth": cam.max_depth,
+                       "parallelism": f"spp-split x{world} + RCCL reduce (asynchronous, overlapping the next step)"
+                       if world > 1 else "single GPU", "mode": "megakernel"},
+            "roofline": dict(roofline_of(wl, m, steps * args.repeats, count), overlap=not args.serial,
+                             launch_interval_ms=med / steps * 1e3 / max(m["n_launches"] / (steps * args.repeats), 1)),
+        }
+        print(f"[bench] {scene_name}: {out['value']:.0f} Mpaths/s over {joined} GPU(s)", file=sys.stderr)
+    wl.close()
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scene_name, args.cpu_paths)
+        if world == 1 and not args.no_configs and not strong and not args.scene:
+            out["configs"] = run_other_configs(args, local_rank)
+        print(json.dumps(out), flush=True)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--scene", default="bouncing_spheres")
-    ap.add_argument("--spp", type=int, default=100, help="samples per pixel per step per GPU")
+    ap.add_argument("--steps", type=int, default=None, help="steps per timed region (default 200; strong scaling 2)")
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions; value is their median")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--scene", default=None, help="default: bouncing_spheres (weak), cornell_box (strong)")
+    ap.add_argument("--spp", type=int, default=0, help="weak: samples per pixel per step per GPU (100); "
+                                                       "strong: per step over all GPUs (16384)")
     ap.add_argument("--width", type=int, default=0, help="override image width (0: the scene's own)")
     ap.add_argument("--serial", action="store_true", help="no overlap between consecutive launches")
     ap.add_argument("--iso-steps", type=int, default=8, help="isolated launches timed for the roofline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the other workloads (configs key)")
     ap.add_argument("--cpu-paths", type=float, default=13.5e6, help="paths of the CPU baseline sample")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher: start the ranks from here.  Nothing in this process has touched the GPU
+        # (counting devices does not initialise it).
+        import torch
 
-    from raytracing_amd import abi, binding, spp_split
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # under torch.distributed.run the collectives run even with one rank (same code path as N > 1)
-    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    if args.gpus != world and rank == 0:
-        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE {world}: using {world}", file=sys.stderr)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-
-    arrays = abi.SceneArrays.load(os.path.join(GOLD, args.scene + ".rtscene"))
-    cam, _ = abi.load_camera_file(os.path.join(GOLD, args.scene + ".cam"))
-    if args.width:
-        cam.image_width = args.width
-    cam.samples_per_pixel = args.spp * world
-    H, W = cam.image_height(), cam.image_width
-    scene = binding.Scene(arrays, device=local_rank)
-    info = scene.info()
-    accum = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
-
-    render_fn = spp_split.gpu_render_fn(scene, cam, seed=0, overlap=not args.serial)
-    render_alone = spp_split.gpu_render_fn(scene, cam, seed=0, overlap=False)
-
-    def step(fn=render_fn):
-        # rank r renders global samples [r*spp, (r+1)*spp); one RCCL sum-reduce to rank 0
-        spp_split.render_split(fn, accum, args.spp * world)
-
-    # one instrumented, untimed pass: rays and test counts of exactly the work a step does
-    st = scene.render_device(cam, args.spp, accum.data_ptr(), stream=stream, sample_begin=rank * args.spp,
-                             seed=0, counters=True)
-    paths_per_step, rays_per_step = int(st.paths), int(st.rays)
-    alg_flops = algorithmic_flops(st)
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    scene.profile_begin()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    kernel_ms, n_launches = scene.profile_end()
-    # the same launches one at a time: the render kernel's own duration
-    iso_ms, iso_launches = kernel_ms, n_launches
-    if not args.serial and args.iso_steps > 0:
-        torch.cuda.synchronize()
-        scene.profile_begin()
-        for _ in range(args.iso_steps):
-            step(render_alone)
-        torch.cuda.synchronize()
-        iso_ms, iso_launches = scene.profile_end()
-
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        cnt = torch.tensor([paths_per_step, rays_per_step], dtype=torch.float64, device=dev)
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-        total_paths, total_rays = float(cnt[0].item()), float(cnt[1].item())
-    else:
-        total_paths, total_rays = float(paths_per_step), float(rays_per_step)
-
-    if rank == 0:
-        avg_kernel_s = iso_ms / max(iso_launches, 1) * 1e-3
-        launches_per_step = max(n_launches, 1) / args.steps
-        achieved = alg_flops / launches_per_step / avg_kernel_s / 1e12 if avg_kernel_s > 0 else 0.0
-        out = {
-            "metric": "Mpaths/s",
-            "value": total_paths * args.steps / elapsed * 1e-6,
-            "unit": "Mpaths/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "mrays_per_s": total_rays * args.steps / elapsed * 1e-6,
-            "rays_per_path": total_rays / total_paths,
-            "config": {"workload": f"{args.scene} {W}x{H}, {args.spp} spp per GPU per step, "
-                                   f"max_depth {cam.max_depth}, {info.n_prims} primitives "
-                                   f"({info.n_nodes} BVH nodes, depth {info.bvh_depth}, "
-                                   f"{'LDS' if info.lds_resident else 'HBM'}-resident geometry)",
-                       "scene": args.scene, "width": W, "height": H, "spp_per_gpu_per_step": args.spp,
-                       "max_depth": cam.max_depth, "parallelism": f"spp-split x{world} + RCCL reduce"
-                       if world > 1 else "single GPU", "mode": "megakernel"},
-            "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS,
-                         "traffic": measured_traffic(args.scene, W, H, args.spp), "traffic_unit": "bytes/launch",
-                         "pmc": measured_traffic(args.scene, W, H, args.spp, key="pmc"),
-                         "hbm_gb_per_s": (measured_traffic(args.scene, W, H, args.spp) or 0.0) / avg_kernel_s * 1e-9
-                         if avg_kernel_s > 0 else None,  # against ~8000: the path is not HBM-bound
-                         "kernel": "render_mega_bvh" if info.n_nodes else "render_mega", "kernel_ms_avg": avg_kernel_s * 1e3,
-                         "kernel_ms_overlapped_avg": kernel_ms / max(n_launches, 1),
-                         "launch_interval_ms": elapsed / max(n_launches, 1) * 1e3,
-                         "launches": n_launches, "isolated_launches": iso_launches,
-                         "overlap": not args.serial, "algorithmic_flops_per_launch": alg_flops / launches_per_step,
-                         "counts_per_launch": {"paths": st.paths, "rays": st.rays, "box_tests": st.box_tests,
-                                               "sphere_tests": st.sphere_tests, "sphere_hits": st.sphere_hits,
-                                               "quad_tests": st.quad_tests, "shades": list(st.shades)}},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.scene, args.cpu_paths)
-        print(json.dumps(out))
-    scene.close()
-    if use_dist:
-        dist.destroy_process_group()
+        from raytracing_amd import spp_split
+        n = torch.cuda.device_count()
+        if n < args.gpus:
+            print(f"[bench] --gpus {args.gpus} but only {n} GPU(s) are visible: refusing to run fewer ranks",
+                  file=sys.stderr)
+            sys.exit(2)
+        codes = spp_split.relaunch_as_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:])
+        if any(codes):
+            print(f"[bench] rank exit codes {codes}", file=sys.stderr)
+            sys.exit(1)
+        sys.exit(0)
+    sys.exit(run_rank(args))
 
 
 if __name__ == "__main__":

@@ -70,6 +70,43 @@ def test_two_ranks_reduce_to_the_single_process_image(tmp_path, world, spp_total
     assert got.sum() > 0
 
 
+def test_spawned_ranks_and_pipelined_reduce(tmp_path):
+    """The launcher bench.py --gpus N uses (spp_split.spawn_ranks: fresh processes with RANK /
+    WORLD_SIZE / MASTER_* set) and the frame pipeline whose reduce overlaps the next render, on
+    CPU with gloo: same image as one process; a rank that dies takes the job down with a
+    non-zero exit code instead of leaving the others waiting."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "acc.npy")
+    env = dict(os.environ, PYTHONPATH=root)
+    codes = spp_split.spawn_ranks(2, [sys.executable, "-m", "tests.split_worker", "6", out], env=env, timeout=300)
+    assert codes == [0, 0]
+    arrays, cam, _ = load_scene("quads")
+    cam.image_width = 48
+    ref, _ = O.OracleScene(arrays).render(cam, 6, sampler=O.SAMPLER_CB, trace_mode=O.TRACE_REFERENCE, seed=4)
+    assert np.allclose(np.load(out), ref, rtol=1e-6, atol=1e-6)
+    codes = spp_split.spawn_ranks(2, [sys.executable, "-m", "tests.split_worker", "6", out, "1"], env=env, timeout=300)
+    assert codes[1] == 3 and codes[0] != 0
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    """python bench.py --gpus N without a launcher starts N ranks itself, and refuses (exit code 2)
+    when fewer than N devices are visible instead of reporting a one-rank number as N."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n = torch.cuda.device_count()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(max(n, 1) + 1), "--steps", "1"],
+                       capture_output=True, env=env, timeout=300)
+    assert r.returncode == 2 and b"refusing" in r.stderr and not r.stdout.strip()
+    # ... and a rank refuses a --gpus that is not the number of ranks launched
+    env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--steps", "1"],
+                       capture_output=True, env=env, timeout=300)
+    assert r.returncode == 2 and b"refusing" in r.stderr and not r.stdout.strip()
+
+
 def test_single_process_needs_no_process_group():
     arrays, cam, _ = load_scene("quads")
     cam.image_width = 32

@@ -13,7 +13,7 @@ rc=$?
 tail -n 15 $O/tests.log
 [ $rc -ne 0 ] && exit $rc
 for sc in bouncing_spheres cornell_box perlin_spheres quads earth simple_light checkered_spheres; do
-  timeout -k 10 200 python bench.py --scene $sc --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_$sc.json 2> $O/bench_$sc.err || { echo "bench $sc failed"; tail -n 5 $O/bench_$sc.err; exit 1; }
+  timeout -k 10 200 python bench.py --scene $sc --steps 20 --warmup 3 --no-cpu-baseline --no-configs > $O/bench_$sc.json 2> $O/bench_$sc.err || { echo "bench $sc failed"; tail -n 5 $O/bench_$sc.err; exit 1; }
   python - $O/bench_$sc.json <<'PY'
 import json,sys
 d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])

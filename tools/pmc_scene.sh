@@ -7,8 +7,8 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/$TAG
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --steps 3 --warmup 1 --serial --no-cpu-baseline --scene $SCENE $*"
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --steps 10 --warmup 2 --serial --no-cpu-baseline --scene $SCENE "$@" > $O/bench_serial.json 2> $O/bench_serial.err || { echo "kernel trace failed"; tail -n 5 $O/bench_serial.err; exit 1; }
+B="python3 $R/bench.py --steps 3 --warmup 1 --serial --no-cpu-baseline --no-configs --scene $SCENE $*"
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --steps 10 --warmup 2 --serial --no-cpu-baseline --no-configs --scene $SCENE "$@" > $O/bench_serial.json 2> $O/bench_serial.err || { echo "kernel trace failed"; tail -n 5 $O/bench_serial.err; exit 1; }
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE --output-format csv -d $O/pmc1 -- $B > $O/pmc1.log 2>&1 || { echo "pmc1 failed"; tail -n 5 $O/pmc1.log; exit 1; }
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS --output-format csv -d $O/pmc2 -- $B > $O/pmc2.log 2>&1 || { echo "pmc2 failed"; tail -n 5 $O/pmc2.log; exit 1; }
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_f -- $B > $O/pmc_f.log 2>&1 || { echo "pmc_f failed"; exit 1; }
