@@ -342,6 +342,24 @@ int rt_film_wait(rt_film *film, uint8_t *rgb8_out, float *accum_out, int64_t *sa
  * Synchronises the film's stream. */
 int rt_film_upload(rt_film *film, const float *accum_host, int64_t samples);
 
+/* ---- several GPUs of one node behind one call -----------------------------
+ * No counterpart in the reference, whose camera::render (camera.h:31-63) is one thread on one
+ * CPU: the sample loop (camera.h:40-47) partitioned over GPUs.  rt_multi_create uploads a
+ * replica of the scene to every listed device (a device may be listed more than once).
+ * rt_multi_render splits samples [sample_begin, +sample_count) into contiguous balanced shares
+ * (share k of n: begin = k*(c/n) + min(k, c%n), one more sample for k < c%n), renders share k
+ * on device k (one host thread per device), copies the per-device fp32 images to the first
+ * device (peer copies, one xGMI link per source), adds them there in device order and ADDS the
+ * total to accum_host.  Every (pixel, sample) path is keyed by its global sample index, so the
+ * image equals the one-device image up to the order of the fp32 additions.  stats (may be
+ * NULL): paths and rays summed over devices, kernel_ms the slowest device's. */
+typedef struct rt_multi rt_multi;
+int rt_multi_create(const rt_scene_desc *desc, const int32_t *devices, int32_t n_devices, uint32_t flags,
+                    rt_multi **out);
+int rt_multi_destroy(rt_multi *multi);
+int rt_multi_render(rt_multi *multi, const rt_camera_desc *cam, const rt_render_opts *opts,
+                    float *accum_host, rt_render_stats *stats);
+
 /* Per-launch timing of the render kernel: between begin and end the library
  * brackets every render-kernel launch of this scene with HIP events on the
  * stream it is launched on; end waits for them and returns the summed

@@ -19,7 +19,7 @@ EXPORTS = ["rt_last_error", "rt_abi_version", "rt_device_count", "rt_camera_init
            "rt_scene_create", "rt_scene_destroy", "rt_scene_get_info", "rt_scene_read_nodes", "rt_trace_batch",
            "rt_trace_batch_device", "rt_trace_batch_sched", "rt_trace_batch_sched_device", "rt_render", "rt_render_device", "rt_render_device_static", "rt_tonemap_u8", "rt_tonemap_u8_device",
            "rt_film_create", "rt_film_destroy", "rt_film_render", "rt_film_snapshot", "rt_film_wait",
-           "rt_film_upload", "rt_profile_begin", "rt_profile_end", "rt_scene_file_save", "rt_scene_file_load",
+           "rt_film_upload", "rt_multi_create", "rt_multi_destroy", "rt_multi_render", "rt_profile_begin", "rt_profile_end", "rt_scene_file_save", "rt_scene_file_load",
            "rt_scene_file_free"]
 
 
@@ -68,6 +68,11 @@ def lib():
             L.rt_film_snapshot.argtypes = [C.c_void_p, C.c_int]
             L.rt_film_wait.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
             L.rt_film_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        L.rt_multi_create.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(C.c_int32), C.c_int32, C.c_uint32,
+                                      C.POINTER(C.c_void_p)]
+        L.rt_multi_destroy.argtypes = [C.c_void_p]
+        L.rt_multi_render.argtypes = [C.c_void_p, C.POINTER(abi.CameraDesc), C.POINTER(abi.RenderOpts), C.c_void_p,
+                                      C.POINTER(abi.RenderStats)]
         L.rt_profile_begin.argtypes = [C.c_void_p]
         L.rt_profile_end.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.rt_scene_file_save.argtypes = [C.POINTER(abi.SceneDesc), C.c_char_p]
@@ -181,6 +186,36 @@ class Scene:
         ms, n = C.c_double(), C.c_int()
         check(lib().rt_profile_end(self.handle, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+
+class MultiScene:
+    """Replicas of a scene on several GPUs of one node (rt_multi_create .. rt_multi_destroy)."""
+
+    def __init__(self, arrays: abi.SceneArrays, devices, flags=0):
+        self.arrays = arrays
+        d = arrays.desc()
+        devs = (C.c_int32 * len(devices))(*devices)
+        h = C.c_void_p()
+        check(lib().rt_multi_create(C.byref(d), devs, len(devices), flags, C.byref(h)))
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib().rt_multi_destroy(self.handle)
+            self.handle = None
+
+    __del__ = close
+
+    def render(self, cam, sample_count, sample_begin=0, seed=0, accum=None, want_stats=True):
+        """Samples [sample_begin, +sample_count) split over the devices; returns (accum, stats)."""
+        H, W = cam.image_height(), cam.image_width
+        if accum is None:
+            accum = np.zeros((H, W, 3), np.float32)
+        o = abi.RenderOpts(sample_begin, sample_count, seed, abi.RT_MODE_MEGAKERNEL, 0)
+        st = abi.RenderStats() if want_stats else None
+        check(lib().rt_multi_render(self.handle, C.byref(cam), C.byref(o), accum.ctypes.data,
+                                    C.byref(st) if st is not None else None))
+        return accum, st
 
 
 class Film:

@@ -16,6 +16,7 @@
 #include <new>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rt_amd.h"
@@ -1257,6 +1258,184 @@ int rt_scene_file_load(const char *path, rt_scene_desc **out) {
 void rt_scene_file_free(rt_scene_desc *desc) { free(desc); }
 
 } // extern "C"
+
+// ---------------------------------------------------------------------------------------
+// Several GPUs of one node behind one call: a replica of the scene per device, the sample range
+// split into contiguous balanced shares (device k of n renders the k-th), one host thread per
+// device for the enqueue, the per-device images gathered on the first device by peer copies
+// (xGMI, one link per source device, in parallel) and added there in device order.
+struct rt_multi {
+    std::vector<int> devices;
+    std::vector<rt_scene *> scenes;
+    std::vector<float *> d_accum;   // per device, W*H*3 floats
+    std::vector<float *> d_gather;  // on devices[0]: one landing buffer per other device
+    std::vector<hipStream_t> streams;
+    std::vector<hipEvent_t> done;
+    float *h_accum = nullptr; // pinned
+    size_t cap_values = 0;
+};
+
+namespace {
+// the split of spp_split.sample_range (raytracing_amd/spp_split.py)
+void multi_share(int total, int k, int n, int *begin, int *count) {
+    const int base = total / n, extra = total % n;
+    *begin = k * base + std::min(k, extra);
+    *count = base + (k < extra ? 1 : 0);
+}
+
+void multi_free_buffers(rt_multi *m) {
+    for (size_t k = 0; k < m->devices.size(); k++) {
+        hipSetDevice(m->devices[k]);
+        if (k < m->d_accum.size() && m->d_accum[k]) hipFree(m->d_accum[k]);
+    }
+    if (!m->devices.empty()) hipSetDevice(m->devices[0]);
+    for (float *p : m->d_gather)
+        if (p) hipFree(p);
+    if (m->h_accum) hipHostFree(m->h_accum);
+    m->d_accum.assign(m->devices.size(), nullptr);
+    m->d_gather.assign(m->devices.size(), nullptr);
+    m->h_accum = nullptr;
+    m->cap_values = 0;
+}
+} // namespace
+
+extern "C" int rt_multi_destroy(rt_multi *m) {
+    if (!m) return RT_OK;
+    for (size_t k = 0; k < m->devices.size(); k++) {
+        hipSetDevice(m->devices[k]);
+        if (k < m->streams.size() && m->streams[k]) {
+            hipStreamSynchronize(m->streams[k]);
+            hipStreamDestroy(m->streams[k]);
+        }
+        if (k < m->done.size() && m->done[k]) hipEventDestroy(m->done[k]);
+    }
+    multi_free_buffers(m);
+    for (rt_scene *s : m->scenes) rt_scene_destroy(s);
+    delete m;
+    return RT_OK;
+}
+
+static int impl_rt_multi_create(const rt_scene_desc *desc, const int32_t *devices, int32_t n_devices, uint32_t flags,
+                                rt_multi **out) {
+    if (!out) return fail(RT_ERR_ARG, "out is null");
+    *out = nullptr;
+    if (!devices || n_devices < 1 || n_devices > 64) return fail(RT_ERR_ARG, "between 1 and 64 devices");
+    rt_multi *m = new rt_multi();
+    m->devices.assign(devices, devices + n_devices);
+    m->d_accum.assign(n_devices, nullptr);
+    m->d_gather.assign(n_devices, nullptr);
+    m->streams.assign(n_devices, nullptr);
+    m->done.assign(n_devices, nullptr);
+    for (int k = 0; k < n_devices; k++) {
+        rt_scene *s = nullptr;
+        int rc = rt_scene_create(desc, devices[k], flags, &s); // (leaves that device current)
+        if (rc == RT_OK && hipStreamCreateWithFlags(&m->streams[k], hipStreamNonBlocking) != hipSuccess)
+            rc = fail(RT_ERR_HIP, "stream for device %d", devices[k]);
+        if (rc == RT_OK && hipEventCreateWithFlags(&m->done[k], hipEventDisableTiming) != hipSuccess)
+            rc = fail(RT_ERR_HIP, "event for device %d", devices[k]);
+        if (s) m->scenes.push_back(s);
+        if (rc != RT_OK) {
+            std::string keep = g_err;
+            rt_multi_destroy(m);
+            g_err = keep;
+            return rc;
+        }
+        if (k > 0 && devices[k] != devices[0]) { // direct copies over xGMI where the node allows them
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, devices[0], devices[k]) == hipSuccess && can) {
+                hipSetDevice(devices[0]);
+                hipError_t e = hipDeviceEnablePeerAccess(devices[k], 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+            }
+        }
+    }
+    *out = m;
+    return RT_OK;
+}
+
+static int impl_rt_multi_render(rt_multi *m, const rt_camera_desc *cam, const rt_render_opts *opts, float *accum_host,
+                                rt_render_stats *stats) {
+    if (!m || !cam || !opts || !accum_host) return fail(RT_ERR_ARG, "null argument");
+    if (opts->sample_count < 0 || opts->sample_begin < 0) return fail(RT_ERR_ARG, "negative sample range");
+    rt_camera_frame fr;
+    int rc = rt_camera_initialize(cam, &fr);
+    if (rc != RT_OK) return rc;
+    const size_t n_values = (size_t)fr.image_width * fr.image_height * 3;
+    const int n = (int)m->devices.size();
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (opts->sample_count == 0) return RT_OK;
+    if (n_values > m->cap_values) {
+        multi_free_buffers(m);
+        for (int k = 0; k < n; k++) {
+            rc = set_device(m->devices[k]);
+            if (rc != RT_OK) return rc;
+            RT_HIP(hipMalloc((void **)&m->d_accum[k], n_values * sizeof(float)));
+        }
+        rc = set_device(m->devices[0]);
+        if (rc != RT_OK) return rc;
+        for (int k = 1; k < n; k++) RT_HIP(hipMalloc((void **)&m->d_gather[k], n_values * sizeof(float)));
+        RT_HIP(hipHostMalloc((void **)&m->h_accum, n_values * sizeof(float), hipHostMallocDefault));
+        m->cap_values = n_values;
+    }
+    std::vector<int> rcs((size_t)n, RT_OK);
+    std::vector<std::string> errs((size_t)n);
+    std::vector<rt_render_stats> sts((size_t)n);
+    auto work = [&](int k) {
+        rcs[k] = guarded("rt_multi_render", [&]() -> int {
+            int r = set_device(m->devices[k]);
+            if (r != RT_OK) return r;
+            rt_render_opts o = *opts;
+            multi_share(opts->sample_count, k, n, &o.sample_begin, &o.sample_count);
+            o.sample_begin += opts->sample_begin;
+            RT_HIP(hipMemsetAsync(m->d_accum[k], 0, n_values * sizeof(float), m->streams[k]));
+            memset(&sts[k], 0, sizeof(sts[k]));
+            if (o.sample_count > 0) {
+                r = rt_render_device(m->scenes[k], cam, &o, m->d_accum[k], m->streams[k], stats ? &sts[k] : nullptr);
+                if (r != RT_OK) return r;
+            }
+            RT_HIP(hipEventRecord(m->done[k], m->streams[k]));
+            return RT_OK;
+        });
+        if (rcs[k] != RT_OK) errs[k] = g_err; // (thread-local in the worker)
+    };
+    {
+        std::vector<std::thread> pool;
+        for (int k = 1; k < n; k++) pool.emplace_back(work, k);
+        work(0);
+        for (std::thread &t : pool) t.join();
+    }
+    for (int k = 0; k < n; k++)
+        if (rcs[k] != RT_OK) return fail(rcs[k], "device %d: %s", m->devices[k], errs[k].c_str());
+    // gather on the first device: every other image over its own link, added in device order
+    rc = set_device(m->devices[0]);
+    if (rc != RT_OK) return rc;
+    hipStream_t s0 = m->streams[0];
+    for (int k = 1; k < n; k++) {
+        RT_HIP(hipStreamWaitEvent(s0, m->done[k], 0));
+        RT_HIP(hipMemcpyPeerAsync(m->d_gather[k], m->devices[0], m->d_accum[k], m->devices[k], n_values * sizeof(float), s0));
+    }
+    for (int k = 1; k < n; k++) RT_HIP(rtl::launch_accum_add(m->d_accum[0], m->d_gather[k], (long long)n_values, s0));
+    RT_HIP(hipMemcpyAsync(m->h_accum, m->d_accum[0], n_values * sizeof(float), hipMemcpyDeviceToHost, s0));
+    RT_HIP(hipStreamSynchronize(s0));
+    for (size_t i = 0; i < n_values; i++) accum_host[i] += m->h_accum[i];
+    if (stats) {
+        for (int k = 0; k < n; k++) {
+            stats->paths += sts[k].paths;
+            stats->rays += sts[k].rays;
+            stats->kernel_ms = std::max(stats->kernel_ms, sts[k].kernel_ms);
+        }
+    }
+    return RT_OK;
+}
+
+extern "C" int rt_multi_create(const rt_scene_desc *desc, const int32_t *devices, int32_t n_devices, uint32_t flags,
+                               rt_multi **out) {
+    return guarded("rt_multi_create", [&] { return impl_rt_multi_create(desc, devices, n_devices, flags, out); });
+}
+extern "C" int rt_multi_render(rt_multi *m, const rt_camera_desc *cam, const rt_render_opts *opts, float *accum_host,
+                               rt_render_stats *stats) {
+    return guarded("rt_multi_render", [&] { return impl_rt_multi_render(m, cam, opts, accum_host, stats); });
+}
 
 extern "C" int rt_scene_create(const rt_scene_desc *d, int device, uint32_t flags, rt_scene **out) {
     return guarded("rt_scene_create", [&] { return impl_rt_scene_create(d, device, flags, out); });

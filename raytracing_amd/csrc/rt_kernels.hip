@@ -578,6 +578,12 @@ __global__ void __launch_bounds__(256) reduce_stage(const f4 *stage, int n_pixel
         atomicAdd(ray_count, wave_rays[0] + wave_rays[1] + wave_rays[2] + wave_rays[3]);
 }
 
+// dst[i] += src[i]: the per-GPU accumulation images of a multi-GPU render, summed in device order.
+__global__ void __launch_bounds__(256) accum_add(float *dst, const float *src, long long n) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+
 // write_color (color.h:17-32) for one colour component per lane.
 __global__ void __launch_bounds__(256) tonemap_u8(const float *accum, long long n, float scale, uint8_t *rgb8) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -841,6 +847,12 @@ hipError_t launch_reduce(const f4 *stage, int n_pixels, int sample_count, float 
     int grid = (n_pixels + 255) / 256;
     hipLaunchKernelGGL(reduce_stage, dim3(grid), dim3(256), 0, stream, stage, n_pixels, sample_count, accum,
                        ray_count, strip_cost);
+    return hipGetLastError();
+}
+
+hipError_t launch_accum_add(float *dst, const float *src, long long n, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(accum_add, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dst, src, n);
     return hipGetLastError();
 }
 

@@ -112,6 +112,7 @@ hipError_t build_lbvh(const float *boxes, const int *types, int n, float *nodes_
                       int *inner_levels);
 hipError_t static_scratch_setup(int device); // the device must be current
 void *static_scratch(int device);
+hipError_t launch_accum_add(float *dst, const float *src, long long n, hipStream_t stream);
 hipError_t launch_tonemap(const float *accum, long long n_components, float scale, uint8_t *rgb8,
                           hipStream_t stream);
 hipError_t launch_trace(const rtc::DevScene &sc, const rt_ray *rays, long long n, float tmin, float tmax,

@@ -1017,6 +1017,10 @@ class camera {
     // Extensions (not in the reference): which GPU renders, and the sampler seed.
     int device = 0;
     uint32_t seed = 0;
+    // Several GPUs of one node: with more than one entry here (or in the environment variable
+    // RTAMD_DEVICES, e.g. "0,1,2,3,4,5,6,7") the samples per pixel are split across these devices
+    // and the per-device images are summed on the first one (rt_multi_render).
+    std::vector<int> devices;
     // Progressive rendering (not in the reference, which writes the image once at the end,
     // camera.h:56): with pass_samples > 0 the image is accumulated on the GPU in passes of that
     // many samples per pixel; after every write_every passes the PNG is rewritten from the
@@ -1070,9 +1074,45 @@ class camera {
         }
         rt_camera_frame frame;
         if (rt_camera_initialize(&cd, &frame) != RT_OK) die("rt_camera_initialize");
-        rt_scene *scene = nullptr;
-        if (rt_scene_create(&sd, device, 0, &scene) != RT_OK) die("rt_scene_create");
         const int W = frame.image_width, H = frame.image_height;
+        std::vector<int> devs = devices;
+        if (const char *e = getenv("RTAMD_DEVICES")) {
+            devs.clear();
+            for (const char *p = e; *p;) {
+                char *end = nullptr;
+                long v = strtol(p, &end, 10);
+                if (end == p) break;
+                devs.push_back((int)v);
+                p = *end == ',' ? end + 1 : end;
+            }
+        }
+        if (devs.size() > 1) { // the sample loop split over several GPUs
+            std::clog << "\rScan lines remaining: " << H << ' ' << std::flush;
+            rt_multi *multi = nullptr;
+            std::vector<int32_t> d32(devs.begin(), devs.end());
+            if (rt_multi_create(&sd, d32.data(), (int32_t)d32.size(), 0, &multi) != RT_OK) die("rt_multi_create");
+            std::vector<float> accum((size_t)W * H * 3, 0.0f);
+            rt_render_opts opts;
+            memset(&opts, 0, sizeof(opts));
+            opts.sample_count = samples_per_pixel;
+            opts.seed = seed;
+            opts.mode = RT_MODE_MEGAKERNEL;
+            rt_render_stats mstats;
+            if (rt_multi_render(multi, &cd, &opts, accum.data(), &mstats) != RT_OK) die("rt_multi_render");
+            std::vector<uint8_t> rgb((size_t)W * H * 3);
+            if (rt_tonemap_u8(accum.data(), (int64_t)W * H, frame.pixel_samples_scale, rgb.data()) != RT_OK)
+                die("rt_tonemap_u8");
+            if (!rtamd::write_png_rgb8(file_name, W, H, rgb.data()))
+                std::cerr << "ERROR: could not write '" << file_name << "'.\n";
+            rt_multi_destroy(multi);
+            std::clog << "\rDone.\n";
+            double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            std::cerr << "Render took " << seconds << " seconds.\n";
+            last_stats = mstats;
+            return;
+        }
+        rt_scene *scene = nullptr;
+        if (rt_scene_create(&sd, devs.size() == 1 ? devs[0] : device, 0, &scene) != RT_OK) die("rt_scene_create");
         int pass = pass_samples, every = write_every;
         std::string ckpt = checkpoint;
         if (const char *e = getenv("RTAMD_PASS_SPP")) pass = atoi(e);
