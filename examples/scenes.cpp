@@ -2,6 +2,7 @@
 // (raytracing_amd/dropin), rendered by librt_amd.so.
 //
 //   rt_scenes <scene> [--spp N] [--width W] [--depth D] [--out file.png] [--dump file.rtscene]
+//                     [--hits file.rays out.hits]
 //
 // The seven scenes restate the reference's main.cpp:14-288 as data; `synth1m` is the
 // 1 000 001-primitive stress scene (no counterpart in the reference).  Random numbers that
@@ -29,8 +30,53 @@ struct View {
 
 static int g_spp = -1, g_width = -1, g_depth = 50;
 static const char *g_out = "RayTracing.png";
+static const char *g_rays_in = nullptr, *g_hits_out = nullptr;
+
+// --hits <file.rays> <out>: instead of rendering, puts the rays of a .rays file (uint64 n, float
+// tmin, tmax, n rt_ray records) through world.hit() on the host and writes n rt_hit records
+// (prim = 0 for a hit: hit_record carries no primitive id).
+static void hits_on_the_host(const hittable &world) {
+    FILE *f = fopen(g_rays_in, "rb");
+    uint64_t n = 0;
+    float range[2];
+    if (!f || fread(&n, 8, 1, f) != 1 || fread(range, 4, 2, f) != 2) {
+        fprintf(stderr, "cannot read %s\n", g_rays_in);
+        exit(1);
+    }
+    std::vector<rt_ray> rays(n);
+    if (fread(rays.data(), sizeof(rt_ray), n, f) != n) exit(1);
+    fclose(f);
+    std::vector<rt_hit> hits(n);
+    for (uint64_t i = 0; i < n; i++) {
+        const rt_ray &q = rays[i];
+        hit_record rec;
+        rt_hit h;
+        memset(&h, 0, sizeof(h));
+        h.prim = -1;
+        if (world.hit(ray(point3(q.orig[0], q.orig[1], q.orig[2]), vec3(q.dir[0], q.dir[1], q.dir[2]), q.tm),
+                      interval(range[0], range[1]), rec)) {
+            h.prim = 0;
+            h.front_face = rec.front_face ? 1 : 0;
+            h.t = rec.t;
+            for (int k = 0; k < 3; k++) {
+                h.p[k] = rec.p[k];
+                h.normal[k] = rec.normal[k];
+            }
+            h.u = rec.u;
+            h.v = rec.v;
+        }
+        hits[i] = h;
+    }
+    f = fopen(g_hits_out, "wb");
+    if (!f || fwrite(hits.data(), sizeof(rt_hit), n, f) != n) exit(1);
+    fclose(f);
+}
 
 static void shoot(const hittable &world, const View &v) {
+    if (g_rays_in) {
+        hits_on_the_host(world);
+        return;
+    }
     camera cam;
     cam.aspect_ratio = v.aspect;
     cam.image_width = g_width > 0 ? g_width : v.width;
@@ -202,7 +248,11 @@ int main(int argc, char **argv) {
     }
     int synth_half = 500;
     for (int i = 2; i + 1 < argc; i += 2) {
-        if (!strcmp(argv[i], "--spp")) g_spp = atoi(argv[i + 1]);
+        if (!strcmp(argv[i], "--hits") && i + 2 < argc) {
+            g_rays_in = argv[i + 1];
+            g_hits_out = argv[i + 2];
+            i++;
+        } else if (!strcmp(argv[i], "--spp")) g_spp = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--width")) g_width = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--depth")) g_depth = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--out")) g_out = argv[i + 1];

@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "rt_amd.h"
+#include "rt_core.h" // the kernels' per-ray arithmetic, compiled for the host: hit(), scatter(), value()
 #include "rt_scene_io.h"
 
 // rt_constants.h:11-17 puts these names at global scope; scene code relies on them
@@ -212,6 +213,8 @@ class aabb {
         if (x.size() > y.size()) return x.size() > z.size() ? 0 : 2;
         return y.size() > z.size() ? 1 : 2;
     }
+    // aabb.h:40-63: slab test on a copy of the interval, one division per axis
+    bool hit(const ray &r, interval ray_t) const;
     static const aabb empty, universe;
 
   private:
@@ -222,6 +225,19 @@ class aabb {
         if (z.size() < delta) z = z.expand(delta);
     }
 };
+inline bool aabb::hit(const ray &r, interval ray_t) const {
+    for (int axis = 0; axis < 3; axis++) {
+        const interval &ax = axis_interval(axis);
+        const float adinv = 1.0f / r.direction()[axis];
+        const float ta = (ax.min - r.origin()[axis]) * adinv, tb = (ax.max - r.origin()[axis]) * adinv;
+        const bool ordered = ta < tb; // (false for NaN: the untouched branch, as in the reference)
+        const float enter = ordered ? ta : tb, leave = ordered ? tb : ta;
+        if (enter > ray_t.min) ray_t.min = enter;
+        if (leave < ray_t.max) ray_t.max = leave;
+        if (ray_t.max <= ray_t.min) return false;
+    }
+    return true;
+}
 inline const aabb aabb::empty = aabb(interval::empty, interval::empty, interval::empty);
 inline const aabb aabb::universe = aabb(interval::universe, interval::universe, interval::universe);
 inline aabb operator+(const aabb &b, const vec3 &o) { return aabb(b.x + o.x(), b.y + o.y(), b.z + o.z()); }
@@ -427,6 +443,11 @@ inline bool write_png_rgb8(const char *path, int w, int h, const uint8_t *rgb) {
 
 } // namespace rtamd
 
+namespace rtamd {
+inline rtc::f3 to_f3(const vec3 &v) { return rtc::mk(v[0], v[1], v[2]); }
+inline vec3 to_vec3(rtc::f3 v) { return vec3(v.x, v.y, v.z); }
+} // namespace rtamd
+
 // ---------------------------------------------------------------------------------------------
 // perlin.h, rtw_stb_image.h, texture.h
 class perlin {
@@ -440,8 +461,15 @@ class perlin {
         generate_perm(table.perm_x);
         generate_perm(scratch); // perm_y: drawn so that the random stream stays aligned
         generate_perm(scratch); // perm_z
+        for (int i = 0; i < 256; i++) { // the layout the kernels' noise code reads
+            dev.randvec[i] = rtc::f4{table.randvec[i][0], table.randvec[i][1], table.randvec[i][2], 0.0f};
+            dev.perm_x[i] = table.perm_x[i];
+        }
     }
     rt_perlin table;
+    rtc::DevPerlin dev;
+    float noise(const point3 &p) const { return rtc::perlin_noise(dev, rtamd::to_f3(p)); }           // perlin.h:17-36
+    float turb(const point3 &p, int depth) const { return rtc::perlin_turb(dev, rtamd::to_f3(p), depth); } // perlin.h:38-50
 
   private:
     static void generate_perm(int32_t *p) {
@@ -549,7 +577,13 @@ class rtw_image {
 class texture {
   public:
     virtual ~texture() = default;
-    virtual int record(rtamd::Recorder &r) const = 0; // returns the texture's index
+    virtual color value(float u, float v, const point3 &p) const = 0; // texture.h:13 (host side)
+    // returns the texture's index in the flat scene; a user-defined texture cannot be flattened
+    virtual int record(rtamd::Recorder &r) const {
+        (void)r;
+        std::cerr << "librt_amd drop-in: a user-defined texture cannot be rendered on the GPU\n";
+        std::exit(1);
+    }
 
   protected:
     int memo(rtamd::Recorder &r, const rt_texture &t) const {
@@ -571,6 +605,7 @@ class solid_color : public texture {
   public:
     solid_color(const color &albedo) : albedo(albedo) {}
     solid_color(float red, float green, float blue) : solid_color(color(red, green, blue)) {}
+    color value(float, float, const point3 &) const override { return albedo; } // texture.h:22-24
     int record(rtamd::Recorder &r) const override {
         rt_texture t = blank(RT_TEX_SOLID);
         for (int k = 0; k < 3; k++) t.color[k] = albedo[k];
@@ -587,6 +622,11 @@ class checker_texture : public texture {
         : inv_scale(1.0f / scale), even(even), odd(odd) {}
     checker_texture(float scale, const color &c1, const color &c2)
         : checker_texture(scale, make_shared<solid_color>(c1), make_shared<solid_color>(c2)) {}
+    color value(float u, float v, const point3 &p) const override { // texture.h:40-47
+        const int cell = int(std::floor(inv_scale * p.x())) + int(std::floor(inv_scale * p.y())) +
+                         int(std::floor(inv_scale * p.z()));
+        return (cell % 2 == 0 ? even : odd)->value(u, v, p);
+    }
     int record(rtamd::Recorder &r) const override {
         auto it = r.texture_ids.find(this);
         if (it != r.texture_ids.end()) return it->second;
@@ -605,6 +645,17 @@ class checker_texture : public texture {
 class image_texture : public texture {
   public:
     image_texture(const char *filename) : image(filename) {}
+    color value(float u, float v, const point3 &) const override { // texture.h:60-74, rtw_stb_image.h:69-79
+        if (image.height() <= 0) return color(0.0f, 0.0f, 1.0f);
+        u = interval(0.0f, 1.0f).clamp(u);
+        v = 1.0f - interval(0.0f, 1.0f).clamp(v);
+        int i = int(u * image.width()), j = int(v * image.height());
+        i = i < 0 ? 0 : (i < image.width() ? i : image.width() - 1);
+        j = j < 0 ? 0 : (j < image.height() ? j : image.height() - 1);
+        const uint8_t *px = &image.bytes()[((size_t)j * image.width() + i) * 3];
+        const float cs = 1.0f / 255.0f;
+        return color(cs * px[0], cs * px[1], cs * px[2]);
+    }
     int record(rtamd::Recorder &r) const override {
         auto it = r.texture_ids.find(this);
         if (it != r.texture_ids.end()) return it->second;
@@ -625,6 +676,9 @@ class image_texture : public texture {
 class noise_texture : public texture {
   public:
     noise_texture(float scale) : scale(scale) {}
+    color value(float, float, const point3 &p) const override { // texture.h:85-90
+        return color(0.5f, 0.5f, 0.5f) * (1.0f + sinf(scale * p.z() + 10.0f * noise.turb(p, 7)));
+    }
     int record(rtamd::Recorder &r) const override {
         auto it = r.texture_ids.find(this);
         if (it != r.texture_ids.end()) return it->second;
@@ -642,10 +696,38 @@ class noise_texture : public texture {
 
 // ---------------------------------------------------------------------------------------------
 // material.h
+class material;
+class hit_record { // hittable.h:10-26
+  public:
+    point3 p;
+    vec3 normal;
+    shared_ptr<material> mat;
+    float t = 0, u = 0, v = 0;
+    bool front_face = false;
+    void set_face_normal(const ray &r, const vec3 &outward_normal) {
+        front_face = dot(r.direction(), outward_normal) < 0;
+        normal = front_face ? outward_normal : -outward_normal;
+    }
+};
+
 class material {
   public:
     virtual ~material() = default;
-    virtual int record(rtamd::Recorder &r) const = 0;
+    // material.h:13-20 (host side): nothing emitted, nothing scattered unless a subclass says so
+    virtual color emitted(float u, float v, const point3 &p) const {
+        (void)u, (void)v, (void)p;
+        return color(0.0f, 0.0f, 0.0f);
+    }
+    virtual bool scatter(const ray &r_in, const hit_record &rec, color &attenuation, ray &scattered) const {
+        (void)r_in, (void)rec, (void)attenuation, (void)scattered;
+        return false;
+    }
+    // index in the flat scene; a user-defined material cannot be flattened
+    virtual int record(rtamd::Recorder &r) const {
+        (void)r;
+        std::cerr << "librt_amd drop-in: a user-defined material cannot be rendered on the GPU\n";
+        std::exit(1);
+    }
 
   protected:
     int memo(rtamd::Recorder &r, const rt_material &m) const {
@@ -664,6 +746,13 @@ class lambertian : public material {
   public:
     lambertian(const color &albedo) : tex(make_shared<solid_color>(albedo)) {}
     lambertian(shared_ptr<texture> tex) : tex(tex) {}
+    bool scatter(const ray &r_in, const hit_record &rec, color &attenuation, ray &scattered) const override {
+        vec3 direction = rec.normal + random_unit_vector(); // material.h:30-42
+        if (direction.near_zero()) direction = rec.normal;
+        scattered = ray(rec.p, direction, r_in.time());
+        attenuation = tex->value(rec.u, rec.v, rec.p);
+        return true;
+    }
     int record(rtamd::Recorder &r) const override {
         int id;
         if (known(r, id)) return id;
@@ -678,6 +767,13 @@ class lambertian : public material {
 class metal : public material {
   public:
     metal(const color &albedo, float fuzz) : albedo(albedo), fuzz(fuzz < 1 ? fuzz : 1) {}
+    bool scatter(const ray &r_in, const hit_record &rec, color &attenuation, ray &scattered) const override {
+        vec3 mirrored = reflect(r_in.direction(), rec.normal); // material.h:53-60
+        mirrored = unit_vector(mirrored) + (fuzz * random_unit_vector());
+        scattered = ray(rec.p, mirrored, r_in.time());
+        attenuation = albedo;
+        return dot(scattered.direction(), rec.normal) > 0;
+    }
     int record(rtamd::Recorder &r) const override {
         int id;
         if (known(r, id)) return id;
@@ -693,6 +789,18 @@ class metal : public material {
 class dielectric : public material {
   public:
     dielectric(float refraction_index) : refraction_index(refraction_index) {}
+    bool scatter(const ray &r_in, const hit_record &rec, color &attenuation, ray &scattered) const override {
+        attenuation = color(1.0f, 1.0f, 1.0f); // material.h:72-90
+        const float ri = rec.front_face ? (1.0f / refraction_index) : refraction_index;
+        const vec3 unit_direction = unit_vector(r_in.direction());
+        const float cos_theta = std::fmin(dot(-unit_direction, rec.normal), 1.0f);
+        const float sin_theta = std::sqrt(1.0f - cos_theta * cos_theta);
+        // the random number is drawn only when refraction is possible (short-circuit, material.h:83)
+        const bool mirror = ri * sin_theta > 1.0f || rtc::schlick(cos_theta, ri) > random_float();
+        scattered = ray(rec.p, mirror ? reflect(unit_direction, rec.normal) : refract(unit_direction, rec.normal, ri),
+                        r_in.time());
+        return true;
+    }
     int record(rtamd::Recorder &r) const override {
         int id;
         if (known(r, id)) return id;
@@ -708,6 +816,7 @@ class diffuse_light : public material {
   public:
     diffuse_light(shared_ptr<texture> tex) : tex(tex) {}
     diffuse_light(const color &emit) : tex(make_shared<solid_color>(emit)) {}
+    color emitted(float u, float v, const point3 &p) const override { return tex->value(u, v, p); } // material.h:113-115
     int record(rtamd::Recorder &r) const override {
         int id;
         if (known(r, id)) return id;
@@ -721,32 +830,34 @@ class diffuse_light : public material {
 
 // ---------------------------------------------------------------------------------------------
 // hittable.h, hittable_list.h, sphere.h, quad.h, bvh.h
-class hit_record { // kept for source compatibility; the GPU kernels have their own record
-  public:
-    point3 p;
-    vec3 normal;
-    shared_ptr<material> mat;
-    float t = 0, u = 0, v = 0;
-    bool front_face = false;
-    void set_face_normal(const ray &r, const vec3 &outward_normal) {
-        front_face = dot(r.direction(), outward_normal) < 0;
-        normal = front_face ? outward_normal : -outward_normal;
-    }
-};
-
 class hittable {
   public:
     virtual ~hittable() = default;
+    // hittable.h:34-36.  Host side: the arithmetic of the kernels (rt_core.h compiled for the host),
+    // so that code that calls hit() itself sees what the renderer sees.
+    virtual bool hit(const ray &r, interval ray_t, hit_record &rec) const = 0;
     virtual aabb bounding_box() const = 0;
-    // appends this object's primitives, in the order the reference would test them
-    virtual void record(rtamd::Recorder &r) const = 0;
+    // appends this object's primitives, in the order the reference would test them; a
+    // user-defined hittable cannot be flattened
+    virtual void record(rtamd::Recorder &r) const {
+        (void)r;
+        std::cerr << "librt_amd drop-in: a user-defined hittable cannot be rendered on the GPU\n";
+        std::exit(1);
+    }
     virtual void print() const {}
+    virtual shared_ptr<hittable> get_left_child() const { return nullptr; }  // hittable.h:41-47
+    virtual shared_ptr<hittable> get_right_child() const { return nullptr; }
 };
 
 class translate : public hittable {
   public:
     translate(shared_ptr<hittable> object, const vec3 &offset) : object(object), offset(offset) {
         bbox = object->bounding_box() + offset;
+    }
+    bool hit(const ray &r, interval ray_t, hit_record &rec) const override { // hittable.h:57-69
+        if (!object->hit(ray(r.origin() - offset, r.direction(), r.time()), ray_t, rec)) return false;
+        rec.p += offset;
+        return true;
     }
     aabb bounding_box() const override { return bbox; }
     void record(rtamd::Recorder &r) const override {
@@ -789,8 +900,17 @@ class rotate_y : public hittable {
     rotate_y(shared_ptr<hittable> object, float angle) : object(object), angle(angle) {
         float radians = degrees_to_radians(angle);
         float s = sinf(radians), c = cosf(radians);
+        trig = rtc::f4{0.0f, 1.0f, s, c};
         bbox = rtamd::rotated_box(object->bounding_box(),
                                   [=](vec3 v) { return vec3(c * v.x() + s * v.z(), v.y(), -s * v.x() + c * v.z()); });
+    }
+    bool hit(const ray &r, interval ray_t, hit_record &rec) const override { // hittable.h:132-151
+        const ray turned(rtamd::to_vec3(rtc::rot_y_cw(trig, rtamd::to_f3(r.origin()))),
+                         rtamd::to_vec3(rtc::rot_y_cw(trig, rtamd::to_f3(r.direction()))), r.time());
+        if (!object->hit(turned, ray_t, rec)) return false;
+        rec.p = rtamd::to_vec3(rtc::rot_y_ccw(trig, rtamd::to_f3(rec.p)));
+        rec.normal = rtamd::to_vec3(rtc::rot_y_ccw(trig, rtamd::to_f3(rec.normal)));
+        return true;
     }
     aabb bounding_box() const override { return bbox; }
     void record(rtamd::Recorder &r) const override {
@@ -803,6 +923,7 @@ class rotate_y : public hittable {
   private:
     shared_ptr<hittable> object;
     float angle;
+    rtc::f4 trig; // {-, -, sin, cos} as the kernels' wrapper ops hold them
     aabb bbox;
 };
 
@@ -813,12 +934,22 @@ class rotate_xyz : public hittable {
         float sa = sinf(degrees_to_radians(alpha)), ca = cosf(degrees_to_radians(alpha));
         float sb = sinf(degrees_to_radians(beta)), cb = cosf(degrees_to_radians(beta));
         float sg = sinf(degrees_to_radians(gamma)), cg = cosf(degrees_to_radians(gamma));
+        to_object = rtc::rot_matrix_cw(sa, ca, sb, cb, sg, cg);
+        to_world = rtc::rot_matrix_ccw(sa, ca, sb, cb, sg, cg);
         bbox = rtamd::rotated_box(object->bounding_box(), [=](vec3 v) { // hittable.h:284-295
             float vx = cb * cg * v.x() + (sa * sb * cg - sg * ca) * v.y() + (sb * ca * cg + sa * sg) * v.z();
             float vy = cb * sg * v.x() + (ca * cg + sa * sb * sg) * v.y() + (-sa * cg + sg * sb * ca) * v.z();
             float vz = -sb * v.x() + sa * cb * v.y() + ca * cb * v.z();
             return vec3(vx, vy, vz);
         });
+    }
+    bool hit(const ray &r, interval ray_t, hit_record &rec) const override { // hittable.h:251-269
+        const ray turned(rtamd::to_vec3(rtc::mat_apply(to_object, rtamd::to_f3(r.origin()))),
+                         rtamd::to_vec3(rtc::mat_apply(to_object, rtamd::to_f3(r.direction()))), r.time());
+        if (!object->hit(turned, ray_t, rec)) return false;
+        rec.p = rtamd::to_vec3(rtc::mat_apply(to_world, rtamd::to_f3(rec.p)));
+        rec.normal = rtamd::to_vec3(rtc::mat_apply(to_world, rtamd::to_f3(rec.normal)));
+        return true;
     }
     aabb bounding_box() const override { return bbox; }
     void record(rtamd::Recorder &r) const override {
@@ -831,6 +962,7 @@ class rotate_xyz : public hittable {
   private:
     shared_ptr<hittable> object;
     float alpha, beta, gamma;
+    rtc::Mat3 to_object, to_world; // hittable.h:299-307 and 285-293, row by row
     aabb bbox;
 };
 
@@ -838,6 +970,12 @@ class scaling : public hittable {
   public:
     scaling(shared_ptr<hittable> object, const vec3 &scale) : object(object), scale(scale) {
         bbox = object->bounding_box() * scale;
+    }
+    bool hit(const ray &r, interval ray_t, hit_record &rec) const override { // hittable.h:319-334
+        if (!object->hit(ray(r.origin() / scale, r.direction() / scale, r.time()), ray_t, rec)) return false;
+        rec.p *= scale;
+        rec.normal = unit_vector(rec.normal / scale);
+        return true;
     }
     aabb bounding_box() const override { return bbox; }
     void record(rtamd::Recorder &r) const override {
@@ -863,6 +1001,16 @@ class hittable_list : public hittable {
         objects.push_back(object);
         bbox = aabb(bbox, object->bounding_box());
     }
+    bool hit(const ray &r, interval ray_t, hit_record &rec) const override { // hittable_list.h:29-43
+        hit_record candidate;
+        bool any = false;
+        for (const auto &o : objects)
+            if (o->hit(r, interval(ray_t.min, any ? rec.t : ray_t.max), candidate)) {
+                any = true;
+                rec = candidate;
+            }
+        return any;
+    }
     aabb bounding_box() const override { return bbox; }
     void record(rtamd::Recorder &r) const override {
         for (const auto &o : objects) o->record(r);
@@ -887,6 +1035,22 @@ class sphere : public hittable {
         vec3 rvec(radius, radius, radius);
         bbox = aabb(aabb(c1 - rvec, c1 + rvec), aabb(c2 - rvec, c2 + rvec));
         center_vec = c2 - c1;
+    }
+    bool hit(const ray &r, interval ray_t, hit_record &rec) const override { // sphere.h:28-74
+        const rtc::f4 g0{center1[0], center1[1], center1[2], radius};
+        const rtc::f4 g1{is_moving ? center_vec[0] : 0.0f, is_moving ? center_vec[1] : 0.0f,
+                         is_moving ? center_vec[2] : 0.0f, 0.0f};
+        const rtc::f3 o = rtamd::to_f3(r.origin()), d = rtamd::to_f3(r.direction());
+        float t;
+        if (!rtc::sphere_test(g0, g1, o, d, rtc::len2(d), r.time(), ray_t.min, ray_t.max, t)) return false;
+        rec.t = t;
+        rec.p = r.at(t);
+        const vec3 centre = rtamd::to_vec3(rtc::xyz(g0) + r.time() * rtc::xyz(g1));
+        const vec3 outward = (rec.p - centre) / radius;
+        rec.set_face_normal(r, outward);
+        rtc::sphere_uv(rtamd::to_f3(outward), rec.u, rec.v); // sphere.h:96-113
+        rec.mat = mat;
+        return true;
     }
     aabb bounding_box() const override { return bbox; }
     void record(rtamd::Recorder &r) const override {
@@ -918,6 +1082,26 @@ class quad : public hittable {
   public:
     quad(const point3 &Q, const point3 &u, const point3 &v, shared_ptr<material> mat) : Q(Q), u(u), v(v), mat(mat) {
         bbox = aabb(aabb(Q, Q + u + v), aabb(Q + u, Q + v)); // quad.h:25-30
+        const vec3 n = cross(u, v);                          // quad.h:15-20
+        normal = unit_vector(n);
+        D = dot(normal, Q);
+        w = n / dot(n, n);
+    }
+    bool hit(const ray &r, interval ray_t, hit_record &rec) const override { // quad.h:32-91
+        const rtc::f4 g0{normal[0], normal[1], normal[2], D}, g1{Q[0], Q[1], Q[2], w[0]};
+        const rtc::f4 g2{w[1], w[2], u[0], u[1]}, g3{u[2], v[0], v[1], v[2]};
+        float t;
+        if (!rtc::quad_test(g0, g1, g2, g3, rtamd::to_f3(r.origin()), rtamd::to_f3(r.direction()), ray_t.min,
+                            ray_t.max, t))
+            return false;
+        rec.t = t;
+        rec.p = r.at(t);
+        const vec3 planar = rec.p - Q;
+        rec.u = dot(w, cross(planar, v));
+        rec.v = dot(w, cross(u, planar));
+        rec.mat = mat;
+        rec.set_face_normal(r, normal);
+        return true;
     }
     aabb bounding_box() const override { return bbox; }
     void record(rtamd::Recorder &r) const override {
@@ -937,6 +1121,8 @@ class quad : public hittable {
   private:
     point3 Q;
     vec3 u, v;
+    vec3 normal, w;
+    float D;
     shared_ptr<material> mat;
     aabb bbox;
 };
@@ -956,20 +1142,44 @@ inline shared_ptr<hittable_list> box(const point3 &a, const point3 &b, shared_pt
     return sides;
 }
 
-// bvh.h.  The renderer builds its own tree over the flattened primitives; this class only
-// reproduces the ORDER in which the reference's tree would test its leaves (the recursive
+// bvh.h.  The renderer builds its own tree over the flattened primitives; what it takes from
+// this class is the ORDER in which the reference's tree would test its leaves (the recursive
 // std::sort by box minimum along the longest axis, bvh.h:48-75), because that order decides
-// which of two coincident primitives wins.
+// which of two coincident primitives wins.  The tree itself is kept as well, for host code
+// that calls hit() or walks it through get_left_child() / get_right_child().
 class bvh_node : public hittable {
   public:
     bvh_node(hittable_list list) : bvh_node(list.objects, 0, list.objects.size()) {}
     bvh_node(std::vector<shared_ptr<hittable>> &objects, size_t start, size_t end) {
-        order(objects, start, end);
-        leaves.assign(objects.begin() + start, objects.begin() + end);
-        bbox = aabb::empty;
-        for (const auto &o : leaves) bbox = aabb(bbox, o->bounding_box());
+        bbox = aabb::empty; // bvh.h:50-52: the box of the range as it is handed in
+        for (size_t i = start; i < end; i++) bbox = aabb(bbox, objects[i]->bounding_box());
+        const size_t span = end - start;
+        if (span == 1) {
+            left = right = objects[start];
+        } else if (span == 2) {
+            left = objects[start];
+            right = objects[start + 1];
+        } else if (span > 2) {
+            const int axis = bbox.longest_axis();
+            std::sort(objects.begin() + start, objects.begin() + end,
+                      [axis](const shared_ptr<hittable> a, const shared_ptr<hittable> b) {
+                          return a->bounding_box().axis_interval(axis).min < b->bounding_box().axis_interval(axis).min;
+                      });
+            const size_t mid = start + span / 2;
+            left = make_shared<bvh_node>(objects, start, mid);
+            right = make_shared<bvh_node>(objects, mid, end);
+        }
+        leaves.assign(objects.begin() + start, objects.begin() + end); // left to right, each leaf once
+    }
+    bool hit(const ray &r, interval ray_t, hit_record &rec) const override { // bvh.h:77-88
+        if (!left || !bbox.hit(r, ray_t)) return false;
+        const bool hit_left = left->hit(r, ray_t, rec);
+        const bool hit_right = right->hit(r, interval(ray_t.min, hit_left ? rec.t : ray_t.max), rec);
+        return hit_left || hit_right;
     }
     aabb bounding_box() const override { return bbox; }
+    shared_ptr<hittable> get_left_child() const override { return left; }   // bvh.h:143-149
+    shared_ptr<hittable> get_right_child() const override { return right; }
     void record(rtamd::Recorder &r) const override {
         r.begin_bvh();
         for (const auto &o : leaves) o->record(r);
@@ -980,22 +1190,9 @@ class bvh_node : public hittable {
     }
 
   private:
+    shared_ptr<hittable> left, right;
     std::vector<shared_ptr<hittable>> leaves;
     aabb bbox;
-    static void order(std::vector<shared_ptr<hittable>> &objects, size_t start, size_t end) {
-        size_t span = end - start;
-        if (span <= 2) return;
-        aabb bb = aabb::empty;
-        for (size_t i = start; i < end; i++) bb = aabb(bb, objects[i]->bounding_box());
-        int axis = bb.longest_axis();
-        std::sort(objects.begin() + start, objects.begin() + end,
-                  [axis](const shared_ptr<hittable> a, const shared_ptr<hittable> b) {
-                      return a->bounding_box().axis_interval(axis).min < b->bounding_box().axis_interval(axis).min;
-                  });
-        size_t mid = start + span / 2;
-        order(objects, start, mid);
-        order(objects, mid, end);
-    }
 };
 
 // ---------------------------------------------------------------------------------------------

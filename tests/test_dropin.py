@@ -14,6 +14,7 @@ import numpy as np
 import pytest
 
 from raytracing_amd import abi
+from tests import oracle_lib as O
 from tests.conftest import GOLDEN, ROOT, SCENES, load_scene
 
 BIN = os.path.join(ROOT, "examples", "bin")
@@ -114,6 +115,39 @@ def test_synth1m_scene_shape(tmp_path):
     assert 0.70 < frac < 0.80
     cam, frame = abi.load_camera_file(out + ".cam")
     assert (frame.image_width, frame.image_height) == (3840, 2160)
+
+
+@pytest.mark.parametrize("scene", SCENES)
+def test_host_side_hit_matches_the_reference_records(scene, tmp_path):
+    """hittable::hit on the drop-in classes (sphere, quad, hittable_list, bvh_node, the instance
+    wrappers; hittable.h:34-36), called on the host for the rays the reference recorded: hit /
+    miss, t, p, normal and face bit for bit, u / v bit for bit as well (glibc's acosf / atan2f on
+    both sides).  The primitive id has no counterpart in hit_record."""
+    rays_file = os.path.join(GOLDEN, scene + ".rays")
+    out = str(tmp_path / "hits.bin")
+    env = dict(os.environ, RTW_IMAGES=os.path.join(GOLDEN, "images"))
+    subprocess.run([RT_SCENES, scene, "--hits", rays_file, out], check=True, capture_output=True, env=env)
+    rays, ref, tmin, tmax = O.load_rays_file(rays_file)
+    hits = np.fromfile(out, abi.HIT_DT)
+    assert len(hits) == len(ref)
+    m = ref["prim"] >= 0
+    assert np.array_equal(hits["prim"] >= 0, m)
+    for f in ("t", "p", "normal", "front_face", "u", "v"):
+        assert np.array_equal(hits[f][m], ref[f][m]), f
+
+
+def test_host_side_materials_and_textures(tmp_path):
+    """material::scatter / emitted and texture::value on the host (material.h:13-20, texture.h:13):
+    tests/host_virtuals.cpp checks them against closed forms and against the oracle-independent
+    invariants of the reference's formulas; here it only has to build and pass."""
+    exe = str(tmp_path / "host_virtuals")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-I" + os.path.join(ROOT, "raytracing_amd", "dropin"),
+                    "-I" + os.path.join(ROOT, "raytracing_amd", "csrc"), "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "host_virtuals.cpp"), "-o", exe,
+                    "-L" + os.path.join(ROOT, "raytracing_amd", "lib"), "-lrt_amd",
+                    "-Wl,-rpath," + os.path.join(ROOT, "raytracing_amd", "lib")], check=True)
+    r = subprocess.run([exe], capture_output=True)
+    assert r.returncode == 0, r.stdout.decode() + r.stderr.decode()
 
 
 @pytest.mark.gpu
