@@ -58,10 +58,15 @@ template <class F> int guarded(const char *what, F body) {
     }
 }
 
+// (a failed call also leaves its code behind for hipGetLastError(), which the kernel launchers
+// use: taken out here, so that it is not reported again by an unrelated launch later)
 #define RT_HIP(call)                                                                               \
     do {                                                                                           \
         hipError_t e_ = (call);                                                                    \
-        if (e_ != hipSuccess) return fail(RT_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_));     \
+        if (e_ != hipSuccess) {                                                                    \
+            (void)hipGetLastError();                                                               \
+            return fail(RT_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_));                       \
+        }                                                                                          \
     } while (0)
 
 const int kTimelineLaunches = 32;
@@ -1320,6 +1325,11 @@ static int impl_rt_multi_create(const rt_scene_desc *desc, const int32_t *device
     if (!out) return fail(RT_ERR_ARG, "out is null");
     *out = nullptr;
     if (!devices || n_devices < 1 || n_devices > 64) return fail(RT_ERR_ARG, "between 1 and 64 devices");
+    const int visible = rt_device_count();
+    if (visible <= 0) return fail(RT_ERR_HIP, "no HIP device available (this library has no CPU path)");
+    for (int k = 0; k < n_devices; k++)
+        if (devices[k] < 0 || devices[k] >= visible)
+            return fail(RT_ERR_ARG, "device %d out of range (%d visible)", devices[k], visible);
     rt_multi *m = new rt_multi();
     m->devices.assign(devices, devices + n_devices);
     m->d_accum.assign(n_devices, nullptr);
