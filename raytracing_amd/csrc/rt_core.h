@@ -124,6 +124,13 @@ struct DevPerlin {
 enum { TRAV_LINEAR = 0, TRAV_BVH = 1 };
 
 #define RT_XF_F4 7
+// A node is 8 x 16 bytes in global memory.  Copies in LDS are spaced RT_NODE_LDS_F4 x 16 bytes
+// apart: at 128 bytes every node would start in bank 0 and the 64 lanes of a wave, each reading
+// the same word of a different node, would all hit the same four banks.
+#define RT_NODE_F4 8
+#ifndef RT_NODE_LDS_F4
+#define RT_NODE_LDS_F4 9
+#endif
 #define RT_KIND_PRIM(k) ((k)&1)
 #define RT_KIND_MAT(k) (((k) >> 2) & 3)
 #define RT_KIND_TEX(k) (((k) >> 4) & 3)
@@ -617,17 +624,18 @@ RT_HD unsigned umax_(unsigned a, unsigned b) { return a > b ? a : b; }
 // above the stack's top: the farthest child lands lowest, the missed ones above the new top
 // where they do not count.  No branch depends on how many children were hit.
 // TOP: nodes [0, n_top) are read from `top` (the workgroup's LDS) instead of `nodes` (HBM).
-template <bool COUNT, class ST, bool TOP, bool SPILL>
+// NODE_F4: spacing of `nodes` (RT_NODE_F4 in global memory, RT_NODE_LDS_F4 for a copy in LDS).
+template <bool COUNT, class ST, bool TOP, bool SPILL, int NODE_F4 = RT_NODE_F4>
 RT_HD void trav_inner(Trav &tv, const f4 *nodes, float tmin, const ST &st, int ref_bits, Cnt<COUNT> &cn,
                       const f4 *top = nullptr, int n_top = 0) {
     typedef typename ST::elem T;
     f4 q0, q1, q2, q3, q4, q5, q6;
     if (TOP && tv.ref < n_top) { // two explicit paths: LDS reads and global loads, no flat addressing
-        const f4 *n = top + (size_t)tv.ref * 8;
+        const f4 *n = top + (size_t)tv.ref * RT_NODE_LDS_F4;
         q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3], q4 = n[4], q5 = n[5], q6 = n[6];
         if constexpr (COUNT) cn.box += __builtin_bit_cast(int, n[7].x);
     } else {
-        const f4 *n = nodes + (size_t)tv.ref * 8;
+        const f4 *n = nodes + (size_t)tv.ref * NODE_F4;
         q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3], q4 = n[4], q5 = n[5], q6 = n[6];
         if constexpr (COUNT) cn.box += __builtin_bit_cast(int, n[7].x);
     }
@@ -714,14 +722,14 @@ RT_HD void trav_test_leaf(Trav &tv, int leaf_ref, const DevScene &sc, const Scen
 }
 
 // Whole traversal of one ray.
-template <bool COUNT, class ST, bool SPILL = false>
+template <bool COUNT, class ST, bool SPILL = false, int NODE_F4 = RT_NODE_F4>
 RT_HD TraceHit trace_bvh(const DevScene &sc, const SceneView &v, const Ray &r, float tmin, float tmax,
                          const ST &st, Cnt<COUNT> &cn) {
     Trav tv;
     trav_begin(tv, r, tmax);
     while (tv.ref != RT_TRAV_DONE) {
         if (tv.ref >= 0) {
-            trav_inner<COUNT, ST, false, SPILL>(tv, v.nodes, tmin, st, sc.ref_bits, cn);
+            trav_inner<COUNT, ST, false, SPILL, NODE_F4>(tv, v.nodes, tmin, st, sc.ref_bits, cn);
         } else {
             trav_test_leaf<COUNT>(tv, tv.ref, sc, v, r, tmin, cn);
             trav_pop<ST, SPILL>(tv, st, sc.ref_bits);
@@ -993,7 +1001,7 @@ RT_HD bool path_after_trace(const DevScene &sc, const SceneView &vw, const DevCa
 
 // One whole segment of ray_color: trace, then miss / emit / scatter.  Returns true
 // while the path continues; when it returns false ps.L holds the path's radiance.
-template <int TRAV, bool COUNT, class ST, bool SPILL>
+template <int TRAV, bool COUNT, class ST, bool SPILL, int NODE_F4 = RT_NODE_F4>
 RT_HD bool path_step(const DevScene &sc, const SceneView &vw, const DevCamera &cam, PathState &ps,
                      const ST &st, unsigned &n_rays, Cnt<COUNT> &cn) {
     if (ps.depth <= 0) return false; // camera.h:141
@@ -1002,7 +1010,7 @@ RT_HD bool path_step(const DevScene &sc, const SceneView &vw, const DevCamera &c
     if constexpr (TRAV == TRAV_LINEAR)
         h = trace_linear<COUNT>(sc, vw, ps.ray, 0.001f, RT_INF, cn);
     else
-        h = trace_bvh<COUNT, ST, SPILL>(sc, vw, ps.ray, 0.001f, RT_INF, st, cn);
+        h = trace_bvh<COUNT, ST, SPILL, NODE_F4>(sc, vw, ps.ray, 0.001f, RT_INF, st, cn);
     return path_after_trace<COUNT>(sc, vw, cam, ps, h, cn);
 }
 

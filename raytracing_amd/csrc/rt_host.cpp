@@ -216,7 +216,7 @@ int validate(const rt_scene_desc *d) {
 // Bytes of LDS the staged arrays take: slots, nodes, both per-slot records, textures
 // (the latter padded to 16 bytes).  Must match the kernels' staging order.
 size_t scene_lds_bytes(const rtc::DevScene &dv) {
-    size_t words = (size_t)dv.n_slots * dv.slot_f4 + (size_t)dv.n_nodes * 8 + (size_t)dv.n_slots * 2;
+    size_t words = (size_t)dv.n_slots * dv.slot_f4 + (size_t)dv.n_nodes * RT_NODE_LDS_F4 + (size_t)dv.n_slots * 2;
     size_t tex = ((size_t)dv.n_textures * sizeof(rt_texture) + 15) / 16;
     return (words + tex) * sizeof(f4);
 }
@@ -234,7 +234,7 @@ LaunchGeom choose_geom(rt_scene *s, uint32_t flags) {
     rtc::DevScene &dv = s->dev;
     const bool bvh = dv.traversal == rtc::TRAV_BVH;
     const int cap = bvh ? RT_STACK_CAP(s->info.bvh_depth) : 0; // stack entries a ray can need
-    const size_t geom_bytes = ((size_t)dv.n_slots * dv.slot_f4 + (size_t)dv.n_nodes * 8) * sizeof(f4);
+    const size_t geom_bytes = ((size_t)dv.n_slots * dv.slot_f4 + (size_t)dv.n_nodes * RT_NODE_LDS_F4) * sizeof(f4);
     const size_t all_bytes = scene_lds_bytes(dv);
     const int block = std::max(64, std::min(1024, env_int("RT_AMD_BLOCK", 1024) / 64 * 64));
     const int threads_per_cu = rtl::mega_waves_per_simd() * 256;
@@ -300,9 +300,9 @@ LaunchGeom choose_geom(rt_scene *s, uint32_t flags) {
         if (bvh && s->tree_top > 0 && env_int("RT_AMD_TREE_TOP", 1) != 0) {
             size_t taken = stack + (lg.ring ? ring_bytes : 0);
             size_t room = budget > taken ? budget - taken : 0;
-            dv.n_top = (int)std::min<size_t>((size_t)s->tree_top, room / (8 * sizeof(f4)));
+            dv.n_top = (int)std::min<size_t>((size_t)s->tree_top, room / (RT_NODE_LDS_F4 * sizeof(f4)));
             dv.n_top = std::min(dv.n_top, std::max(0, env_int("RT_AMD_TREE_TOP_NODES", dv.n_top)));
-            used += (size_t)dv.n_top * 8 * sizeof(f4);
+            used += (size_t)dv.n_top * RT_NODE_LDS_F4 * sizeof(f4);
         }
     }
     dv.stack_cap = cap;

@@ -78,7 +78,8 @@ __device__ __forceinline__ void wave_traverse(int &state, Trav &tv, int &pend, c
 #pragma unroll
         for (int k = 0; k < RT_INNER_UNROLL; k++) {
             if (trav && tv.ref >= 0)
-                trav_inner<COUNT, ST, !LDS_SCENE, SPILL>(tv, vw.nodes, tmin, st, sc.ref_bits, cn, vw.top, vw.n_top);
+                trav_inner<COUNT, ST, !LDS_SCENE, SPILL, LDS_SCENE ? RT_NODE_LDS_F4 : RT_NODE_F4>(tv, vw.nodes, tmin, st, sc.ref_bits, cn, vw.top,
+                                                                                                     vw.n_top);
             if (trav && tv.ref < 0 && tv.ref != RT_TRAV_DONE && pend == 0) {
                 pend = tv.ref;
                 trav_pop<ST, SPILL>(tv, st, sc.ref_bits);
@@ -218,7 +219,7 @@ render_mega(DevScene sc, DevCamera cam, RenderParams rp) {
                     if constexpr (TRAV == TRAV_LINEAR)
                         h = trace_linear<COUNT>(sc, vw, ps.ray, 0.001f, RT_INF, cn);
                     else
-                        h = trace_bvh<COUNT, Stack, SPILL>(sc, vw, ps.ray, 0.001f, RT_INF, st, cn);
+                        h = trace_bvh<COUNT, Stack, SPILL, LDS_SCENE ? RT_NODE_LDS_F4 : RT_NODE_F4>(sc, vw, ps.ray, 0.001f, RT_INF, st, cn);
                 }
                 long long c1 = clock64();
                 if (go) cont = path_after_trace<COUNT>(sc, vw, cam, ps, h, cn);
@@ -230,7 +231,7 @@ render_mega(DevScene sc, DevCamera cam, RenderParams rp) {
                     w_cycles[4] += __popcll(__ballot(true));
                 }
             } else {
-                cont = path_step<TRAV, COUNT, Stack, SPILL>(sc, vw, cam, ps, st, n_rays, cn);
+                cont = path_step<TRAV, COUNT, Stack, SPILL, LDS_SCENE ? RT_NODE_LDS_F4 : RT_NODE_F4>(sc, vw, cam, ps, st, n_rays, cn);
             }
             if (!cont) {
                 write_record(rp, sample, pixel, ps.L, n_rays);
@@ -268,10 +269,10 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
     if constexpr (LDS_SCENE) free_lds = stage_scene(sc, smem, vw);
     using StackT = typename std::conditional<LDS_SCENE, short, int>::type;
     if constexpr (!LDS_SCENE) { // the scene stays in HBM: the top of the tree comes along
-        stage_to_lds(free_lds, sc.nodes, sc.n_top * 8);
+        stage_nodes_to_lds(free_lds, sc.nodes, sc.n_top);
         vw.top = free_lds;
         vw.n_top = sc.n_top;
-        free_lds += (size_t)sc.n_top * 8;
+        free_lds += (size_t)sc.n_top * RT_NODE_LDS_F4;
         __syncthreads();
     }
     constexpr bool SPILL = !LDS_SCENE;
@@ -663,10 +664,10 @@ trace_sched(DevScene sc, RenderParams rp, const rt_ray *rays, long long n_rays, 
     if constexpr (LDS_SCENE) free_lds = stage_scene(sc, smem, vw);
     using StackT = typename std::conditional<LDS_SCENE, short, int>::type;
     if constexpr (!LDS_SCENE) {
-        stage_to_lds(free_lds, sc.nodes, sc.n_top * 8);
+        stage_nodes_to_lds(free_lds, sc.nodes, sc.n_top);
         vw.top = free_lds;
         vw.n_top = sc.n_top;
-        free_lds += (size_t)sc.n_top * 8;
+        free_lds += (size_t)sc.n_top * RT_NODE_LDS_F4;
         __syncthreads();
     }
     constexpr bool SPILL = !LDS_SCENE;

@@ -12,17 +12,23 @@ __device__ __forceinline__ void stage_to_lds(f4 *dst, const f4 *src, int n) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
 }
 
+// Copies n_nodes nodes (RT_NODE_F4 words apart) to LDS, RT_NODE_LDS_F4 words apart.
+__device__ __forceinline__ void stage_nodes_to_lds(f4 *dst, const f4 *src, int n_nodes) {
+    for (int i = threadIdx.x; i < n_nodes * RT_NODE_F4; i += blockDim.x)
+        dst[(i >> 3) * RT_NODE_LDS_F4 + (i & 7)] = src[i];
+}
+
 // Stages slots, nodes, the per-slot records, the texture table and the Perlin tables into LDS
 // (the layout matches choose_geom() in rt_host.cpp); returns the first free 16-byte word.
 __device__ __forceinline__ f4 *stage_scene(const DevScene &sc, f4 *smem, SceneView &v) {
     int n_slot_words = sc.n_slots * sc.slot_f4;
-    int n_node_words = sc.n_nodes * 8;
+    int n_node_words = sc.n_nodes * RT_NODE_LDS_F4;
     int n_tex_words = (sc.n_textures * (int)sizeof(rt_texture) + 15) / 16;
     f4 *p = smem;
     stage_to_lds(p, sc.slots, n_slot_words);
     v.slots = p;
     p += n_slot_words;
-    stage_to_lds(p, sc.nodes, n_node_words);
+    stage_nodes_to_lds(p, sc.nodes, sc.n_nodes);
     v.nodes = p;
     p += n_node_words;
     if (sc.lds_records) {

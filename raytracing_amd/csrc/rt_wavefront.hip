@@ -147,7 +147,7 @@ wf_trace(DevScene sc, WfBuffers wf, const int *q_trace_cur, int stack_lds_entrie
         if constexpr (TRAV == TRAV_LINEAR)
             h = trace_linear<false>(sc, vw, r, 0.001f, RT_INF, cn);
         else
-            h = trace_bvh<false, Stack, SPILL>(sc, vw, r, 0.001f, RT_INF, stk, cn);
+            h = trace_bvh<false, Stack, SPILL, LDS_SCENE ? RT_NODE_LDS_F4 : RT_NODE_F4>(sc, vw, r, 0.001f, RT_INF, stk, cn);
         // the first 8 bytes of the auxiliary record: {t, slot}
         *reinterpret_cast<float2 *>(&wf.aux[slot]) = float2{h.t, __builtin_bit_cast(float, h.slot)};
         wf.key[i] = h.slot < 0 ? (int)Q_MISS : RT_KIND_MAT(vw.rec_i[h.slot].x);
