@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RT_AMD_ABI_VERSION 2
+#define RT_AMD_ABI_VERSION 3
 
 /* ---- error codes ------------------------------------------------------- */
 enum {
@@ -219,6 +219,10 @@ typedef struct rt_render_stats {
     /* wall-clock profile of the decoupled kernel's launch, microseconds after the first wave
      * started: first / last wave that found the launch out of new paths, last wave exit */
     double tail_us[3];
+    /* how alike the lanes of a wave are in a node step of the decoupled kernel (RT_RENDER_COUNTERS,
+     * BVH scenes): lanes that took part in node steps, and those of them that were at the same
+     * node as the wave's first active lane (the share a wave-uniform fetch of that node would serve) */
+    uint64_t coherence[2];
 } rt_render_stats;
 
 typedef struct rt_scene_info {

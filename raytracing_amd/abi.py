@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-RT_AMD_ABI_VERSION = 2
+RT_AMD_ABI_VERSION = 3
 
 RT_OK, RT_ERR_ARG, RT_ERR_HIP, RT_ERR_UNSUPPORTED, RT_ERR_IO = 0, -1, -2, -3, -4
 RT_PRIM_SPHERE, RT_PRIM_QUAD = 0, 1
@@ -92,7 +92,7 @@ class RenderStats(C.Structure):
                 ("quad_tests", C.c_uint64), ("shades", C.c_uint64 * 4),
                 ("noise_evals", C.c_uint64), ("image_evals", C.c_uint64),
                 ("checker_evals", C.c_uint64), ("sched", C.c_uint64 * 6), ("kernel_ms", C.c_double),
-                ("cycles", C.c_uint64 * 6), ("tail_us", C.c_double * 3)]
+                ("cycles", C.c_uint64 * 6), ("tail_us", C.c_double * 3), ("coherence", C.c_uint64 * 2)]
 
 
 class SceneInfo(C.Structure):

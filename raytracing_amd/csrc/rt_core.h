@@ -203,6 +203,7 @@ struct Counters {
     // wall clock (100 MHz ticks): earliest wave start, first / last moment a wave found the launch
     // out of new paths, last wave exit
     unsigned long long tail[4];
+    unsigned long long coherence[2]; // lanes in node steps; lanes at the same node as the wave's first active lane
 };
 
 template <bool COUNT> struct Cnt {

@@ -902,6 +902,7 @@ static int impl_rt_render_device(rt_scene *s, const rt_camera_desc *cam, const r
             stats->checker_evals = c.checker_evals;
             for (int k = 0; k < 6; k++) stats->sched[k] = c.sched[k];
             for (int k = 0; k < 6; k++) stats->cycles[k] = c.cycles[k];
+            for (int k = 0; k < 2; k++) stats->coherence[k] = c.coherence[k];
             if (c.tail[3] > c.tail[0] && c.tail[0] != ~0ull)
                 for (int k = 0; k < 3; k++) // wall_clock64 ticks at 100 MHz
                     stats->tail_us[k] = c.tail[k + 1] == ~0ull ? 0.0 : (double)(c.tail[k + 1] - c.tail[0]) * 0.01;

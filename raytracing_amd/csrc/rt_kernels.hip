@@ -42,7 +42,7 @@ namespace {
 enum { ST_IDLE = 0, ST_TRAV = 1, ST_READY = 2 };
 
 struct SchedStats { // wave-level schedule statistics (instrumented variants only)
-    unsigned long long t_iters = 0, t_lanes = 0, l_iters = 0, l_lanes = 0;
+    unsigned long long t_iters = 0, t_lanes = 0, l_iters = 0, l_lanes = 0, same_node = 0;
     long long c_inner = 0, c_leaf = 0;
 };
 
@@ -71,6 +71,9 @@ __device__ __forceinline__ void wave_traverse(int &state, Trav &tv, int &pend, c
             if (im0) {
                 ss.t_iters++;
                 ss.t_lanes += __popcll(im0);
+                // lanes that would be served by one wave-uniform fetch of the first lane's node
+                const int leader = __builtin_amdgcn_readlane(tv.ref, __builtin_ctzll(im0));
+                ss.same_node += __popcll(__ballot(state == ST_TRAV && tv.ref == leader));
             }
             c_mark = clock64();
         }
@@ -527,6 +530,8 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
             atomicAdd(&rp.counters->cycles[0], (unsigned long long)(clock64() - c_begin));
             atomicAdd(&rp.counters->cycles[1], (unsigned long long)c_shade);
             atomicAdd(&rp.counters->cycles[2], (unsigned long long)c_regen);
+            atomicAdd(&rp.counters->coherence[0], ss.t_lanes);
+            atomicAdd(&rp.counters->coherence[1], ss.same_node);
             atomicAdd(&rp.counters->cycles[3], (unsigned long long)ss.c_inner);
             atomicAdd(&rp.counters->cycles[4], (unsigned long long)ss.c_leaf);
             atomicMin(&rp.counters->tail[0], w_start);

@@ -876,7 +876,13 @@ class translate : public hittable {
 namespace rtamd {
 // Box of a rotated object as the reference computes it (hittable.h:109-130, 227-248): it
 // takes max[c] = fmax(min[c], corner[c]), so "max" ends up as the larger of the running
-// minimum and the LAST corner.  Kept as is: only the leaf order of a bvh_node depends on it.
+// minimum and the LAST corner: the box is too small.  Kept as is, because the leaf order of a
+// bvh_node depends on it, and that order decides ties.  In the reference the box also culls: a
+// rotate_y / rotate_xyz object INSIDE a bvh_node is clipped to it there (bvh.h:78), and so it is
+// by bvh_node::hit() on the host below.  The GPU renderer does not inherit this: it bounds the
+// flattened primitives itself (correctly) and renders the whole object.  None of the
+// reference's scenes rotates anything inside a bvh_node (main.cpp:260-269 rotate inside a
+// hittable_list, which ignores boxes), so no reference image shows the difference.
 template <class Rot> inline aabb rotated_box(const aabb &b, Rot rot) {
     point3 mn(infinity, infinity, infinity), mx(-infinity, -infinity, -infinity);
     for (int i = 0; i < 2; i++)

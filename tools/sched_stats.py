@@ -20,4 +20,7 @@ c = list(st.cycles)
 if c[0]:
     print(f"wave cycles: shade {c[1]/c[0]:.3f} start paths {c[2]/c[0]:.3f} node steps {c[3]/c[0]:.3f} leaf tests {c[4]/c[0]:.3f} rest {(c[0]-c[1]-c[2]-c[3]-c[4])/c[0]:.3f}"
           f" | cycles per block: node x4 {c[3]/max(s[0],1):.0f} leaf {c[4]/max(s[2],1):.0f} shade {c[1]/max(s[4],1):.0f} start {c[2]/max(s[4],1):.0f}")
+if st.coherence[0]:
+    print(f"node steps: {st.coherence[1] / st.coherence[0]:.3f} of the participating lanes are at the same node as the wave's "
+          f"first active lane ({st.coherence[0] / max(s[0], 1):.1f} lanes per step on average)")
 print(f"launch profile (instrumented kernel): first wave out of new paths at {st.tail_us[0]:.0f} us, last at {st.tail_us[1]:.0f} us, last wave exit {st.tail_us[2]:.0f} us")
