@@ -38,6 +38,27 @@ using namespace rtc;
 
 namespace {
 
+// Leaves a lane has popped but not tested yet (leaf references are negative; 0 = none).
+#ifndef RT_PARKED
+#define RT_PARKED 1
+#endif
+struct Parked {
+    int a = 0, b = 0; // tested in this order
+    __device__ __forceinline__ bool full() const { return RT_PARKED > 1 ? b != 0 : a != 0; }
+    __device__ __forceinline__ void put(int ref) {
+        if (RT_PARKED > 1 && a != 0)
+            b = ref;
+        else
+            a = ref;
+    }
+    __device__ __forceinline__ int take() {
+        const int r = a;
+        a = RT_PARKED > 1 ? b : 0;
+        b = 0;
+        return r;
+    }
+};
+
 // Lane states of the decoupled kernels.
 enum { ST_IDLE = 0, ST_TRAV = 1, ST_READY = 2 };
 
@@ -56,7 +77,7 @@ struct SchedStats { // wave-level schedule statistics (instrumented variants onl
 // lane has an inner node left.  Lanes whose traversal ends leave in ST_READY with the closest
 // hit in tv.best_t / tv.best_slot.
 template <bool LDS_SCENE, bool COUNT, class ST, bool SPILL>
-__device__ __forceinline__ void wave_traverse(int &state, Trav &tv, int &pend, const Ray &ray, const DevScene &sc,
+__device__ __forceinline__ void wave_traverse(int &state, Trav &tv, Parked &pend, const Ray &ray, const DevScene &sc,
                                               const SceneView &vw, const ST &st, float tmin, int min_ready,
                                               int leaf_min, int blocked_min, bool idle_counts, Cnt<COUNT> &cn,
                                               SchedStats &ss) {
@@ -83,8 +104,8 @@ __device__ __forceinline__ void wave_traverse(int &state, Trav &tv, int &pend, c
             if (trav && tv.ref >= 0)
                 trav_inner<COUNT, ST, !LDS_SCENE, SPILL, LDS_SCENE ? RT_NODE_LDS_F4 : RT_NODE_F4>(tv, vw.nodes, tmin, st, sc.ref_bits, cn, vw.top,
                                                                                                      vw.n_top);
-            if (trav && tv.ref < 0 && tv.ref != RT_TRAV_DONE && pend == 0) {
-                pend = tv.ref;
+            if (trav && tv.ref < 0 && tv.ref != RT_TRAV_DONE && !pend.full()) {
+                pend.put(tv.ref);
                 trav_pop<ST, SPILL>(tv, st, sc.ref_bits);
             }
         }
@@ -93,8 +114,8 @@ __device__ __forceinline__ void wave_traverse(int &state, Trav &tv, int &pend, c
             ss.c_inner += now - c_mark;
             c_mark = now;
         }
-        const bool blocked = trav && tv.ref < 0 && tv.ref != RT_TRAV_DONE; // second leaf, slot taken
-        const bool has_pend = trav && pend != 0;
+        const bool blocked = trav && tv.ref < 0 && tv.ref != RT_TRAV_DONE; // another leaf, no slot left
+        const bool has_pend = trav && pend.a != 0;
         unsigned long long pmask = __ballot(has_pend);
         if (pmask != 0ull) {
             unsigned long long imask = __ballot(trav && tv.ref >= 0);
@@ -105,17 +126,16 @@ __device__ __forceinline__ void wave_traverse(int &state, Trav &tv, int &pend, c
                     ss.l_lanes += __popcll(pmask);
                 }
                 if (has_pend) {
-                    trav_test_leaf<COUNT>(tv, pend, sc, vw, ray, tmin, cn);
-                    pend = 0;
+                    trav_test_leaf<COUNT>(tv, pend.take(), sc, vw, ray, tmin, cn);
                     if (blocked) {
-                        pend = tv.ref;
+                        pend.put(tv.ref);
                         trav_pop<ST, SPILL>(tv, st, sc.ref_bits);
                     }
                 }
             }
         }
         if constexpr (COUNT) ss.c_leaf += clock64() - c_mark;
-        if (trav && tv.ref == RT_TRAV_DONE && pend == 0) state = ST_READY;
+        if (trav && tv.ref == RT_TRAV_DONE && pend.a == 0) state = ST_READY;
     }
 }
 
@@ -290,7 +310,7 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
     const int leaf_min = rp.leaf_min;
     const int blocked_min = rp.blocked_min;
     const int regen_min = rp.regen_min;
-    int pend = 0; // parked leaf reference (leaf references are negative; 0 = none)
+    Parked pend;
 
     WavePool wp;
     pool_init(wp);
@@ -482,7 +502,7 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
                                 pixel = __builtin_bit_cast(unsigned, a4.x);
                                 sample = __builtin_bit_cast(unsigned, a4.y);
                                 trav_begin(tv, ps.ray, RT_INF);
-                                pend = 0;
+                                pend = Parked();
                                 state = ST_TRAV;
                             }
                             have_batch = false;
@@ -684,7 +704,8 @@ trace_sched(DevScene sc, RenderParams rp, const rt_ray *rays, long long n_rays, 
     unsigned long long *next_batch = reinterpret_cast<unsigned long long *>(rp.next_chunk);
     long long k = 0, k_end = 0; // the wave's current batch of rays
     bool exhausted = false;
-    int state = ST_IDLE, pend = 0;
+    int state = ST_IDLE;
+    Parked pend;
     long long mine = -1;
     Ray ray;
     Trav tv;
@@ -723,7 +744,7 @@ trace_sched(DevScene sc, RenderParams rp, const rt_ray *rays, long long n_rays, 
                 ray.d = mk(in.dir[0], in.dir[1], in.dir[2]);
                 ray.tm = in.tm;
                 trav_begin(tv, ray, tmax);
-                pend = 0;
+                pend = Parked();
                 state = ST_TRAV;
                 want = false;
             }
