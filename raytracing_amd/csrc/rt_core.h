@@ -315,6 +315,28 @@ RT_HD bool quad_test(f4 g0, f4 g1, f4 g2, f4 g3, f3 o, f3 d, float tmin, float t
     return true;
 }
 
+// The same test as straight-line code: every lane computes everything and the conditions are
+// combined at the end.  Same arithmetic, same result (a denominator below the threshold or a
+// parameter outside the interval still means "no hit", whatever the later terms evaluate to);
+// for scans in which all lanes of a wave test the same quad, where the early exits above only
+// idle the lanes that take them while the others finish.
+RT_HD bool quad_test_straight(f4 g0, f4 g1, f4 g2, f4 g3, f3 o, f3 d, float tmin, float tmax, float &t_out) {
+    f3 n = xyz(g0);
+    float denominator = dot(n, d);
+    float t = (g0.w - dot(n, o)) / denominator;
+    f3 Q = xyz(g1);
+    f3 w = mk(g1.w, g2.x, g2.y);
+    f3 u = mk(g2.z, g2.w, g3.x);
+    f3 v = mk(g3.y, g3.z, g3.w);
+    f3 planar = (o + t * d) - Q;
+    float alpha = dot(w, cross(planar, v));
+    float beta = dot(w, cross(u, planar));
+    bool hit = !(fabsf(denominator) < 1e-8f) & (tmin <= t) & (t <= tmax) & (0.0f <= alpha) & (alpha <= 1.0f) &
+               (0.0f <= beta) & (beta <= 1.0f);
+    t_out = t;
+    return hit;
+}
+
 // ------------------------------------------------------------------------------------------
 // Instance wrappers (hittable.h:51-344), applied to the ray at run time exactly
 // as the reference does; used by the linear traversal, where it costs one ray
@@ -468,7 +490,11 @@ RT_HD TraceHit trace_linear(const DevScene &sc, const SceneView &v, const Ray &r
             if constexpr (COUNT) cn.sphh += h ? 1 : 0;
         } else {
             RT_COUNT(quad);
+#if defined(RT_SCAN_BRANCHY)
             h = quad_test(g[0], g[1], g[2], g[3], o, d, tmin, best.t, t);
+#else
+            h = quad_test_straight(g[0], g[1], g[2], g[3], o, d, tmin, best.t, t);
+#endif
         }
         if (h) {
             best.t = t;
