@@ -638,6 +638,19 @@ template <class ST, bool SPILL> RT_HD void trav_pop(Trav &tv, const ST &st, int 
         tv.ref = stack_entry_ref<int>(st.spill[tv.sp - st.lds_end], ref_bits);
 }
 
+// Offset of LDS node `ref` in 16-byte words.  The spacing of 9 words is not a power of two, and
+// the compiler turns every spelling of ref * 9 back into a full 32-bit multiply, which issues at
+// quarter rate; one shift-and-add does it at full rate.
+RT_HD unsigned lds_node_words(int ref) {
+    static_assert(RT_NODE_LDS_F4 == 9, "the shift-and-add below is ref * 9");
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned w;
+    asm("v_lshl_add_u32 %0, %1, 3, %1" : "=v"(w) : "v"(ref));
+    return w;
+#else
+    return (unsigned)ref * 9u;
+#endif
+}
 RT_HD unsigned umin_(unsigned a, unsigned b) { return a < b ? a : b; }
 RT_HD unsigned umax_(unsigned a, unsigned b) { return a > b ? a : b; }
 
@@ -658,11 +671,11 @@ RT_HD void trav_inner(Trav &tv, const f4 *nodes, float tmin, const ST &st, int r
     typedef typename ST::elem T;
     f4 q0, q1, q2, q3, q4, q5, q6;
     if (TOP && tv.ref < n_top) { // two explicit paths: LDS reads and global loads, no flat addressing
-        const f4 *n = top + (size_t)tv.ref * RT_NODE_LDS_F4;
+        const f4 *n = top + lds_node_words(tv.ref);
         q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3], q4 = n[4], q5 = n[5], q6 = n[6];
         if constexpr (COUNT) cn.box += __builtin_bit_cast(int, n[7].x);
     } else {
-        const f4 *n = nodes + (size_t)tv.ref * NODE_F4;
+        const f4 *n = nodes + (NODE_F4 == RT_NODE_LDS_F4 ? (size_t)lds_node_words(tv.ref) : (size_t)tv.ref * NODE_F4);
         q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3], q4 = n[4], q5 = n[5], q6 = n[6];
         if constexpr (COUNT) cn.box += __builtin_bit_cast(int, n[7].x);
     }
