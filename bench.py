@@ -62,8 +62,10 @@ def algorithmic_flops(st):
 def measured_traffic(scene, width, height, spp, key="traffic_bytes_per_launch"):
     """HBM bytes per launch of the render kernel (or, with key="pmc", its VALU counters) from the
     PMC passes committed under profiles/ (hardware counters cannot be read from inside this
-    process); None if no profile matches the workload."""
-    best = None
+    process); None if no profile matches the workload.  `spp` is the samples per pixel of ONE
+    launch; a profile of the same scene and image taken at another launch size is scaled by the
+    number of paths (the traffic is per-path records and per-ray node fetches)."""
+    best, best_exact = None, False
     pdir = os.path.join(ROOT, "profiles")
     for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
         if not name.endswith("hbm_traffic.json"):
@@ -72,9 +74,14 @@ def measured_traffic(scene, width, height, spp, key="traffic_bytes_per_launch"):
             with open(os.path.join(pdir, name)) as f:
                 t = json.load(f)
             w = t["workload"]
-            if (w["scene"], w["width"], w["height"], w["spp_per_launch"]) == (scene, width, height, spp):
-                best = t[key] if key == "pmc" else float(t[key])
-        except (OSError, KeyError, ValueError):
+            if (w["scene"], w["width"], w["height"]) != (scene, width, height) or spp <= 0:
+                continue
+            exact = abs(w["spp_per_launch"] - spp) < 1e-9
+            if best is not None and best_exact and not exact:
+                continue
+            best = t[key] if key == "pmc" else float(t[key]) * spp / w["spp_per_launch"]
+            best_exact = exact
+        except (OSError, KeyError, ValueError, ZeroDivisionError):
             continue
     return best
 
@@ -210,10 +217,11 @@ def roofline_of(wl, m, steps_total, spp_per_launch_hint):
     avg_kernel_s = m["iso_ms"] / max(m["iso_launches"], 1) * 1e-3
     launches_per_step = max(m["n_launches"], 1) / steps_total
     achieved = alg / launches_per_step / avg_kernel_s / 1e12 if avg_kernel_s > 0 else 0.0
-    traffic = measured_traffic(wl.name, wl.W, wl.H, spp_per_launch_hint)
+    spp_launch = spp_per_launch_hint / launches_per_step
+    traffic = measured_traffic(wl.name, wl.W, wl.H, spp_launch)
     return {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
-            "pmc": measured_traffic(wl.name, wl.W, wl.H, spp_per_launch_hint, key="pmc"),
+            "pmc": measured_traffic(wl.name, wl.W, wl.H, spp_launch, key="pmc"),
             "hbm_gb_per_s": (traffic / avg_kernel_s * 1e-9) if traffic and avg_kernel_s > 0 else None,
             "hbm_frac_of_peak": (traffic / avg_kernel_s * 1e-9 / PEAK_HBM_GBS) if traffic and avg_kernel_s > 0 else None,
             "kernel": wl.kernel_name(), "kernel_ms_avg": avg_kernel_s * 1e3,
@@ -235,7 +243,10 @@ def load_workload(name, width=0):
         if not os.path.exists(prog):
             return None
         out = "/tmp/bench_synth1m.rtscene"
-        subprocess.run([prog, "synth1m", "--half", "500", "--dump", out], check=True, capture_output=True)
+        fresh = (os.path.exists(out) and os.path.exists(out + ".cam")
+                 and os.path.getmtime(out) >= os.path.getmtime(prog))
+        if not fresh:  # (a profiler run generates it beforehand, see tools/pmc_scene.sh)
+            subprocess.run([prog, "synth1m", "--half", "500", "--dump", out], check=True, capture_output=True)
         arrays = abi.SceneArrays.load(out)
         cam = abi.load_camera_file(out + ".cam")[0]
     else:

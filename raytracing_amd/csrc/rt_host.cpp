@@ -226,6 +226,13 @@ int env_int(const char *name, int dflt) {
     return e ? atoi(e) : dflt;
 }
 
+// Dynamic LDS one workgroup may use when `bpc` of them share a CU: each also holds the kernels'
+// static part, and the hardware hands LDS out in blocks (1 KB of slack covers the rounding).
+size_t lds_budget(int bpc) {
+    if (bpc <= 1) return (size_t)kMaxLdsBytes;
+    return (size_t)(160 * 1024) / bpc - RT_BLOCK_POOL_BYTES - 1024;
+}
+
 // Workgroup shape of the persistent render kernel and what it stages into LDS.  The
 // kernels are compiled for mega_waves_per_simd() waves per SIMD; a CU is filled with
 // that many waves if the per-workgroup LDS (scene copy + traversal stacks) allows it.
@@ -254,7 +261,7 @@ LaunchGeom choose_geom(rt_scene *s, uint32_t flags) {
     size_t used = 0; // scene copy / tree top + stacks: where the rings start
     if (!(flags & RT_SCENE_FORCE_GLOBAL) && short_ok) {
         for (bpc = bpc_target; bpc >= 1 && !lg.lds_scene; bpc--) {
-            size_t budget = (size_t)kMaxLdsBytes / bpc;
+            size_t budget = lds_budget(bpc);
             size_t stack = (size_t)cap * RT_MEGA_MAX_THREADS * sizeof(short); // rows of the full workgroup size
             if (all_bytes + stack <= budget) {
                 lg.lds_scene = true;
@@ -293,8 +300,9 @@ LaunchGeom choose_geom(rt_scene *s, uint32_t flags) {
         dv.ref_bits = std::max(16, std::min(32, bits + 1));
         lg.stack_lds_entries = bvh ? std::max(4, std::min(cap, env_int("RT_AMD_LDS_STACK", 24))) : 0;
         size_t stack = (size_t)lg.stack_lds_entries * RT_MEGA_MAX_THREADS * sizeof(int);
-        bpc = std::max(1, std::min(bpc_target, (int)(kMaxLdsBytes / std::max<size_t>(stack + ring_bytes, 1))));
-        size_t budget = (size_t)kMaxLdsBytes / bpc;
+        bpc = bpc_target;
+        while (bpc > 1 && lds_budget(bpc) < stack + ring_bytes) bpc--;
+        size_t budget = lds_budget(bpc);
         lg.ring = ring_bytes && stack + ring_bytes <= budget;
         used = stack;
         if (bvh && s->tree_top > 0 && env_int("RT_AMD_TREE_TOP", 1) != 0) {

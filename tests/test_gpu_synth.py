@@ -70,6 +70,7 @@ def _assert_same_hits(arrays, rays, hits, ref, max_frac=1e-3):
     exceeds the radius.  A BVH, the reference's own included, culls most of those.  Such
     rays may differ; they must be rare and every one of them must be of that kind."""
     bad = np.nonzero((hits["prim"] != ref["prim"]) | (hits["t"] != ref["t"]))[0]
+    print(f"differing rays: {len(bad)} of {len(rays)} ({len(bad) / max(len(rays), 1):.4f})")
     assert len(bad) <= max(1, int(len(rays) * max_frac)), f"{len(bad)} of {len(rays)} rays differ"
     for i in bad:
         phantom = False
@@ -124,13 +125,13 @@ def test_synth_full_grid(tmp_path):
     rays = _camera_rays(cam, 150, rng)
     hits = sc.trace(rays)
     oh, _ = osc.trace(rays, 0.001, np.inf, O.TRACE_REFERENCE)
-    # with a million spheres up to 650 units away, a few per cent of the rays find a
+    # with a million spheres up to 650 units away, one to two per cent of the rays find a
     # rounding-dominated hit somewhere in the exhaustive scan
-    _assert_same_hits(arrays, rays, hits, oh, max_frac=0.05)
+    _assert_same_hits(arrays, rays, hits, oh, max_frac=0.025)
     rays2 = _secondary_rays(hits, rng)
     h2 = sc.trace(rays2)
     o2, _ = osc.trace(rays2, 0.001, np.inf, O.TRACE_REFERENCE)
-    _assert_same_hits(arrays, rays2, h2, o2, max_frac=0.05)
+    _assert_same_hits(arrays, rays2, h2, o2, max_frac=0.025)
     # render: the two variants walk the tree in different orders (the megakernel defers leaf
     # tests), which is invisible except for the rounding-dominated hits above, whose t is not
     # bounded by their box: all but a few pixels in 10^5 are identical bit for bit
@@ -346,6 +347,6 @@ def test_device_built_bvh(tmp_path):
     print(f"synth1m build: device {di.build_ms:.0f} ms (depth {di.bvh_depth}), host {hi.build_ms:.0f} ms (depth {hi.bvh_depth})")
     assert di.built_on_device == 1 and 300_000 <= di.n_nodes < 1_000_000 and di.bvh_depth <= 30
     hd, hh = dev.trace(rays), host.trace(rays)
-    _assert_same_hits(arrays, rays, hd, hh, max_frac=0.05)
+    _assert_same_hits(arrays, rays, hd, hh, max_frac=0.025)
     dev.close()
     host.close()

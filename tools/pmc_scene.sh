@@ -7,6 +7,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/$TAG
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
+[ "$SCENE" = synth1m ] && { $R/examples/bin/rt_scenes synth1m --half 500 --dump /tmp/bench_synth1m.rtscene > /dev/null || exit 1; }
 B="python3 $R/bench.py --steps 3 --warmup 1 --serial --no-cpu-baseline --no-configs --scene $SCENE $*"
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --steps 10 --warmup 2 --serial --no-cpu-baseline --no-configs --scene $SCENE "$@" > $O/bench_serial.json 2> $O/bench_serial.err || { echo "kernel trace failed"; tail -n 5 $O/bench_serial.err; exit 1; }
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE --output-format csv -d $O/pmc1 -- $B > $O/pmc1.log 2>&1 || { echo "pmc1 failed"; tail -n 5 $O/pmc1.log; exit 1; }
