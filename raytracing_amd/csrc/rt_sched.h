@@ -1,0 +1,116 @@
+// rt_sched.h — the traversal half of the decoupled scheduling scheme, shared by the render
+// kernel (render_mega_bvh), the batch query that uses the render kernel's traversal
+// (trace_sched) and the wavefront variant's trace kernel (wf_trace).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "rt_core.h"
+
+#ifndef RT_INNER_UNROLL
+#define RT_INNER_UNROLL 2
+#endif
+
+namespace rtc {
+
+// Leaves a lane has popped but not tested yet (leaf references are negative; 0 = none).
+#ifndef RT_PARKED
+#define RT_PARKED 1
+#endif
+struct Parked {
+    int a = 0, b = 0; // tested in this order
+    __device__ __forceinline__ bool full() const { return RT_PARKED > 1 ? b != 0 : a != 0; }
+    __device__ __forceinline__ void put(int ref) {
+        if (RT_PARKED > 1 && a != 0)
+            b = ref;
+        else
+            a = ref;
+    }
+    __device__ __forceinline__ int take() {
+        const int r = a;
+        a = RT_PARKED > 1 ? b : 0;
+        b = 0;
+        return r;
+    }
+};
+
+// Lane states of the decoupled kernels.
+enum { ST_IDLE = 0, ST_TRAV = 1, ST_READY = 2 };
+
+struct SchedStats { // wave-level schedule statistics (instrumented variants only)
+    unsigned long long t_iters = 0, t_lanes = 0, l_iters = 0, l_lanes = 0, same_node = 0;
+    long long c_inner = 0, c_leaf = 0;
+};
+
+// The traversal half of the decoupled scheme, shared by the render kernel and by the batch
+// kernel that puts caller-supplied rays through the same code (trace_sched): runs node steps
+// for the lanes in ST_TRAV, RT_INNER_UNROLL per scheduling decision, until `min_ready` lanes
+// wait for something else (a finished traversal, or — if idle lanes can be given new work,
+// `idle_counts` — nothing at all) or no lane traverses any more.  A leaf does not stop its
+// lane: it is parked in the lane's `pend` and the traversal goes on; parked leaves are tested
+// together once leaf_min lanes hold one, blocked_min lanes have run into a second leaf, or no
+// lane has an inner node left.  Lanes whose traversal ends leave in ST_READY with the closest
+// hit in tv.best_t / tv.best_slot.
+template <bool LDS_SCENE, bool COUNT, class ST, bool SPILL>
+__device__ __forceinline__ void wave_traverse(int &state, Trav &tv, Parked &pend, const Ray &ray, const DevScene &sc,
+                                              const SceneView &vw, const ST &st, float tmin, int min_ready,
+                                              int leaf_min, int blocked_min, bool idle_counts, Cnt<COUNT> &cn,
+                                              SchedStats &ss) {
+    long long c_mark = 0;
+    for (;;) {
+        unsigned long long tmask = __ballot(state == ST_TRAV);
+        if (tmask == 0ull) break;
+        unsigned long long rmask = __ballot(state == ST_READY || (state == ST_IDLE && idle_counts));
+        if (__popcll(rmask) >= min_ready) break;
+        if constexpr (COUNT) {
+            unsigned long long im0 = __ballot(state == ST_TRAV && tv.ref >= 0);
+            if (im0) {
+                ss.t_iters++;
+                ss.t_lanes += __popcll(im0);
+                // lanes that would be served by one wave-uniform fetch of the first lane's node
+                const int leader = __builtin_amdgcn_readlane(tv.ref, __builtin_ctzll(im0));
+                ss.same_node += __popcll(__ballot(state == ST_TRAV && tv.ref == leader));
+            }
+            c_mark = clock64();
+        }
+        const bool trav = state == ST_TRAV;
+#pragma unroll
+        for (int k = 0; k < RT_INNER_UNROLL; k++) {
+            if (trav && tv.ref >= 0)
+                trav_inner<COUNT, ST, !LDS_SCENE, SPILL, LDS_SCENE ? RT_NODE_LDS_F4 : RT_NODE_F4>(tv, vw.nodes, tmin, st, sc.ref_bits, cn, vw.top,
+                                                                                                     vw.n_top);
+            if (trav && tv.ref < 0 && tv.ref != RT_TRAV_DONE && !pend.full()) {
+                pend.put(tv.ref);
+                trav_pop<ST, SPILL>(tv, st, sc.ref_bits);
+            }
+        }
+        if constexpr (COUNT) {
+            const long long now = clock64();
+            ss.c_inner += now - c_mark;
+            c_mark = now;
+        }
+        const bool blocked = trav && tv.ref < 0 && tv.ref != RT_TRAV_DONE; // another leaf, no slot left
+        const bool has_pend = trav && pend.a != 0;
+        unsigned long long pmask = __ballot(has_pend);
+        if (pmask != 0ull) {
+            unsigned long long imask = __ballot(trav && tv.ref >= 0);
+            unsigned long long bmask = __ballot(blocked);
+            if (__popcll(pmask) >= leaf_min || __popcll(bmask) >= blocked_min || imask == 0ull) {
+                if constexpr (COUNT) {
+                    ss.l_iters++;
+                    ss.l_lanes += __popcll(pmask);
+                }
+                if (has_pend) {
+                    trav_test_leaf<COUNT>(tv, pend.take(), sc, vw, ray, tmin, cn);
+                    if (blocked) {
+                        pend.put(tv.ref);
+                        trav_pop<ST, SPILL>(tv, st, sc.ref_bits);
+                    }
+                }
+            }
+        }
+        if constexpr (COUNT) ss.c_leaf += clock64() - c_mark;
+        if (trav && tv.ref == RT_TRAV_DONE && pend.a == 0) state = ST_READY;
+    }
+}
+
+} // namespace rtc

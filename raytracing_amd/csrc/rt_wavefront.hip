@@ -21,6 +21,7 @@
 
 #include "rt_core.h"
 #include "rt_launch.h"
+#include "rt_sched.h"
 #include "rt_stage.h"
 
 using namespace rtc;
@@ -118,11 +119,14 @@ wf_generate(DevCamera cam, RenderParams rp, WfBuffers wf, int *q_trace_cur) {
 __global__ void wf_advance(unsigned *cnt) { cnt[C_POOL] += cnt[C_GEN_COUNT]; }
 
 // Persistent: one workgroup per CU stages the geometry into LDS once per launch; its waves
-// take batches of 64 queued rays with a grid stride, one whole ray per lane.  Writes the hit
-// and, per queue position, the key of the queue the ray goes to next.
+// take batches of 64 queued rays, wave w the batches w, w + (waves of the grid), ...  Linear
+// scenes: one whole ray per lane.  BVH scenes: the decoupled scheme of the render kernel
+// (wave_traverse: blocks of node steps, parked leaves); a lane whose ray is done writes its
+// result and takes the next ray of the wave's batch, so the wave does not wait for its slowest
+// ray.  Writes the hit and, per queue position, the key of the queue the ray goes to next.
 template <int TRAV, bool LDS_SCENE>
 __global__ void __launch_bounds__(RT_MEGA_MAX_THREADS, RT_MEGA_WAVES_PER_SIMD)
-wf_trace(DevScene sc, WfBuffers wf, const int *q_trace_cur, int stack_lds_entries, int *stack_spill) {
+wf_trace(DevScene sc, WfBuffers wf, const int *q_trace_cur, RenderParams rp) {
     extern __shared__ f4 smem[];
     SceneView vw = global_view(sc);
     f4 *free_lds = smem;
@@ -130,27 +134,88 @@ wf_trace(DevScene sc, WfBuffers wf, const int *q_trace_cur, int stack_lds_entrie
     if (blockIdx.x * blockDim.x >= n) return; // nothing for this workgroup: skip the staging
     if constexpr (LDS_SCENE) free_lds = stage_scene(sc, smem, vw);
     using StackT = typename std::conditional<LDS_SCENE, short, int>::type;
+    if constexpr (!LDS_SCENE && TRAV == TRAV_BVH) { // the scene stays in HBM: the top of the tree comes along
+        stage_nodes_to_lds(free_lds, sc.nodes, sc.n_top);
+        vw.top = free_lds;
+        vw.n_top = sc.n_top;
+        free_lds += (size_t)sc.n_top * RT_NODE_LDS_F4;
+        __syncthreads();
+    }
     constexpr bool SPILL = !LDS_SCENE;
     typedef TravStack<StackT, RT_MEGA_MAX_THREADS> Stack;
-    const Stack stk = lane_stack<StackT, SPILL, RT_MEGA_MAX_THREADS>(free_lds, sc, stack_lds_entries, stack_spill);
+    const Stack stk = lane_stack<StackT, SPILL, RT_MEGA_MAX_THREADS>(free_lds, sc, rp.stack_lds_entries, rp.stack_spill);
     Cnt<false> cn;
-    const unsigned stride = gridDim.x * blockDim.x;
-    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        int slot = q_trace_cur[i];
-        const f4 *st = wf.state + 4 * (size_t)slot;
-        f4 o = st[0], d = st[1];
-        Ray r;
-        r.o = mk(o.x, o.y, o.z);
-        r.d = mk(d.x, d.y, d.z);
-        r.tm = o.w;
-        TraceHit h;
-        if constexpr (TRAV == TRAV_LINEAR)
-            h = trace_linear<false>(sc, vw, r, 0.001f, RT_INF, cn);
-        else
-            h = trace_bvh<false, Stack, SPILL, LDS_SCENE ? RT_NODE_LDS_F4 : RT_NODE_F4>(sc, vw, r, 0.001f, RT_INF, stk, cn);
-        // the first 8 bytes of the auxiliary record: {t, slot}
-        *reinterpret_cast<float2 *>(&wf.aux[slot]) = float2{h.t, __builtin_bit_cast(float, h.slot)};
-        wf.key[i] = h.slot < 0 ? (int)Q_MISS : RT_KIND_MAT(vw.rec_i[h.slot].x);
+    if constexpr (TRAV == TRAV_LINEAR) {
+        const unsigned stride = gridDim.x * blockDim.x;
+        for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+            int slot = q_trace_cur[i];
+            const f4 *st = wf.state + 4 * (size_t)slot;
+            f4 o = st[0], d = st[1];
+            Ray r;
+            r.o = mk(o.x, o.y, o.z);
+            r.d = mk(d.x, d.y, d.z);
+            r.tm = o.w;
+            TraceHit h = trace_linear<false>(sc, vw, r, 0.001f, RT_INF, cn);
+            // the first 8 bytes of the auxiliary record: {t, slot}
+            *reinterpret_cast<float2 *>(&wf.aux[slot]) = float2{h.t, __builtin_bit_cast(float, h.slot)};
+            wf.key[i] = h.slot < 0 ? (int)Q_MISS : RT_KIND_MAT(vw.rec_i[h.slot].x);
+        }
+    } else {
+        const int lane = threadIdx.x & 63;
+        const unsigned long long lane_mask_lt = (1ull << lane) - 1ull;
+        const unsigned n_waves = gridDim.x * (blockDim.x >> 6);
+        const unsigned n_batches = (n + 63u) / 64u;
+        unsigned batch = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); // the wave's next batch
+        unsigned k = 0, k_end = 0;                                             // what is left of its current one
+        int state = ST_IDLE;
+        Parked pend;
+        unsigned mine = 0;
+        int slot = 0;
+        Ray ray;
+        Trav tv;
+        SchedStats ss;
+        for (;;) {
+            if (state == ST_READY) {
+                *reinterpret_cast<float2 *>(&wf.aux[slot]) = float2{tv.best_t, __builtin_bit_cast(float, tv.best_slot)};
+                wf.key[mine] = tv.best_slot < 0 ? (int)Q_MISS : RT_KIND_MAT(vw.rec_i[tv.best_slot].x);
+                state = ST_IDLE;
+            }
+            unsigned long long need = __ballot(state == ST_IDLE);
+            bool want = state == ST_IDLE;
+            for (int pass = 0; pass < 2 && need != 0ull && (k < k_end || batch < n_batches); pass++) {
+                if (k >= k_end) {
+                    k = batch * 64u;
+                    k_end = k + 64u < n ? k + 64u : n;
+                    batch += n_waves;
+                }
+                const unsigned avail = k_end - k;
+                const unsigned r = (unsigned)__popcll(need & lane_mask_lt);
+                const bool take = want && r < avail;
+                if (take) {
+                    mine = k + r;
+                    slot = q_trace_cur[mine];
+                    const f4 *st = wf.state + 4 * (size_t)slot;
+                    const f4 o = st[0], d = st[1];
+                    ray.o = mk(o.x, o.y, o.z);
+                    ray.d = mk(d.x, d.y, d.z);
+                    ray.tm = o.w;
+                    trav_begin(tv, ray, RT_INF);
+                    pend = Parked();
+                    state = ST_TRAV;
+                    want = false;
+                }
+                const unsigned n_need = (unsigned)__popcll(need);
+                k += n_need < avail ? n_need : avail;
+                need &= ~__ballot(take);
+            }
+            const bool more = k < k_end || batch < n_batches;
+            if (!__any(state != ST_IDLE)) {
+                if (!more) break;
+                continue;
+            }
+            wave_traverse<LDS_SCENE, false, Stack, SPILL>(state, tv, pend, ray, sc, vw, stk, 0.001f, rp.min_ready, rp.leaf_min,
+                                                           rp.blocked_min, more, cn, ss);
+        }
     }
 }
 
@@ -277,14 +342,14 @@ hipError_t render_wavefront(const DevScene &sc, const DevCamera &cam, const Rend
             hipLaunchKernelGGL(wf_advance, dim3(1), dim3(1), 0, stream, wf.cnt);
             if (sc.traversal == TRAV_LINEAR) {
                 if (lg.lds_scene)
-                    hipLaunchKernelGGL((wf_trace<TRAV_LINEAR, true>), dim3(lg.grid), dim3(lg.block), lg.lds_bytes, stream, sc, wf, cur, rp.stack_lds_entries, rp.stack_spill);
+                    hipLaunchKernelGGL((wf_trace<TRAV_LINEAR, true>), dim3(lg.grid), dim3(lg.block), lg.lds_bytes, stream, sc, wf, cur, rp);
                 else
-                    hipLaunchKernelGGL((wf_trace<TRAV_LINEAR, false>), dim3(lg.grid), dim3(lg.block), lg.lds_bytes, stream, sc, wf, cur, rp.stack_lds_entries, rp.stack_spill);
+                    hipLaunchKernelGGL((wf_trace<TRAV_LINEAR, false>), dim3(lg.grid), dim3(lg.block), lg.lds_bytes, stream, sc, wf, cur, rp);
             } else {
                 if (lg.lds_scene)
-                    hipLaunchKernelGGL((wf_trace<TRAV_BVH, true>), dim3(lg.grid), dim3(lg.block), lg.lds_bytes, stream, sc, wf, cur, rp.stack_lds_entries, rp.stack_spill);
+                    hipLaunchKernelGGL((wf_trace<TRAV_BVH, true>), dim3(lg.grid), dim3(lg.block), lg.lds_bytes, stream, sc, wf, cur, rp);
                 else
-                    hipLaunchKernelGGL((wf_trace<TRAV_BVH, false>), dim3(lg.grid), dim3(lg.block), lg.lds_bytes, stream, sc, wf, cur, rp.stack_lds_entries, rp.stack_spill);
+                    hipLaunchKernelGGL((wf_trace<TRAV_BVH, false>), dim3(lg.grid), dim3(lg.block), lg.lds_bytes, stream, sc, wf, cur, rp);
             }
             hipLaunchKernelGGL(wf_classify, dim3(big_grid), dim3(1024), 0, stream, wf, cur);
             hipLaunchKernelGGL(wf_shade, dim3(big_grid), dim3(1024), 0, stream, sc, cam, rp, wf, next);

@@ -44,9 +44,13 @@ def test_render_matches_oracle_path_for_path(scene):
     ref, ost = osc.render(cam, spp, sampler=O.SAMPLER_CB, trace_mode=O.TRACE_REFERENCE, seed=3,
                           n_threads=8)
     assert st.paths == ost.paths
-    # ray counts: forked paths (see below) change the count; independent renders of this size
-    # differ by about 0.6 % (seed to seed), same-seed GPU vs oracle must stay well inside that
-    assert abs(int(st.rays) - int(ost.rays)) <= 6e-3 * ost.rays
+    # ray counts: a forked path (see below) changes the count, nothing else does.  Scenes of quads
+    # and solid / image textures have no fork (no sin / cos in the shading of a hit: 0 rays of
+    # difference); the others stay within a few forks' worth (measured: checkered 2e-4, cornell
+    # 1.4e-4, bouncing 2.1e-3, perlin 2.5e-3, simple_light 3.1e-3 of the rays), well inside the
+    # 0.6 % by which independent renders of this size differ seed to seed
+    ray_bound = {"quads": 0.0, "earth": 0.0, "checkered_spheres": 1e-3, "cornell_box": 1e-3}.get(scene, 5e-3)
+    assert abs(int(st.rays) - int(ost.rays)) <= ray_bound * ost.rays
     diff = np.abs(acc - ref)
     tol = 1e-4 * np.maximum(1.0, np.abs(ref))
     frac_bad = float((diff > tol).any(axis=2).mean())
