@@ -112,7 +112,8 @@ struct DevPerlin {
 //   kind = prim type | material type << 2 | texture type << 4 (texture type of the
 //   material's texture; a solid colour is inlined into rec_f and texture = -1)
 // rec_f: per slot {r g b param}: lambertian / light with a solid texture: the colour;
-//   metal: albedo + fuzz; dielectric: (1,1,1) + refraction index
+//   metal: albedo + fuzz; dielectric: {1/ri, Schlick's r0 from outside, r0 from inside, ri}
+//   (ri = refraction index; the attenuation (1,1,1) is implied)
 // nodes: 4-wide BVH, the child boxes stored in the parent, 128 bytes (layout: trav_inner);
 //   ref >= 0: inner node index; ref < 0: leaf, ~ref = slot*2 + type
 // textures: only the textures reachable from a non-solid material texture (re-indexed)
@@ -955,12 +956,15 @@ RT_HD f3 refract(f3 uv, f3 n, float etai_over_etat) {             // vec3.h:169
     f3 r_out_parallel = -sqrtf(fabsf(1.0f - len2(r_out_perp))) * n;
     return r_out_perp + r_out_parallel;
 }
-RT_HD float schlick(float cosine, float ri) { // material.h:97-103
-    float r0 = (1.0f - ri) / (1.0f + ri);
-    r0 = r0 * r0;
+RT_HD float schlick_r0(float cosine, float r0) { // material.h:101-102, r0 given
     float x = 1.0f - cosine;
     float x2 = x * x;
     return r0 + (1.0f - r0) * (x2 * x2 * x);
+}
+RT_HD float schlick(float cosine, float ri) { // material.h:97-103
+    float r0 = (1.0f - ri) / (1.0f + ri);
+    r0 = r0 * r0;
+    return schlick_r0(cosine, r0);
 }
 
 // Returns true while the path continues.
@@ -970,7 +974,7 @@ RT_HD bool shade_hit(const DevScene &sc, const SceneView &vw, int slot, PathStat
     const int kind = s.rec.x;
     const int mat = RT_KIND_MAT(kind);
     const f4 rf = vw.rec_f[slot];
-    // colour of the material's texture: inlined when solid
+    // colour of the material's texture: inlined when solid (dielectric: see below)
     f3 col = mk(rf.x, rf.y, rf.z);
     if ((mat == RT_MAT_LAMBERTIAN || mat == RT_MAT_DIFFUSE_LIGHT) && RT_KIND_TEX(kind) != RT_TEX_SOLID)
         col = texture_value<COUNT>(sc, vw, s.rec.y, s, cn);
@@ -982,13 +986,17 @@ RT_HD bool shade_hit(const DevScene &sc, const SceneView &vw, int slot, PathStat
     f3 dir;
     if (mat == RT_MAT_DIELECTRIC) { // material.h:72-90
         RT_COUNT(sh2);
-        float ri = s.front ? (1.0f / rf.w) : rf.w;
+        // the record holds {1/ri, r0 seen from outside, r0 seen from inside, ri}: the host has done
+        // the divisions of material.h:76 and 99, in the same fp32 arithmetic
+        float ri = s.front ? rf.x : rf.w;
+        float r0 = s.front ? rf.y : rf.z;
+        col = mk(1.0f, 1.0f, 1.0f);
         f3 unit_direction = unit(ps.ray.d);
         float cos_theta = fminf(dot(-unit_direction, s.n), 1.0f);
         float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
         bool cannot_refract = ri * sin_theta > 1.0f;
         float xi = rng_next(ps.rng);
-        if (cannot_refract || schlick(cos_theta, ri) > xi)
+        if (cannot_refract || schlick_r0(cos_theta, r0) > xi)
             dir = reflect(unit_direction, s.n);
         else
             dir = refract(unit_direction, s.n, ri);

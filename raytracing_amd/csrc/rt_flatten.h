@@ -772,8 +772,15 @@ inline int flatten_scene(const rt_scene_desc *d, uint32_t flags, HostScene &out,
                 }
             } else if (mat.type == RT_MAT_METAL) {
                 rf = f4{mat.albedo[0], mat.albedo[1], mat.albedo[2], mat.param};
-            } else { // dielectric: attenuation (1,1,1), material.h:74
-                rf = f4{1.0f, 1.0f, 1.0f, mat.param};
+            } else {
+                // dielectric (attenuation (1,1,1), material.h:74): what scatter() derives from the
+                // refraction index alone, computed once here in the same fp32 operations
+                // (material.h:76 1/ri; material.h:99-100 Schlick's r0 for either side)
+                const float ior = mat.param, inv = 1.0f / ior;
+                float r0_front = (1.0f - inv) / (1.0f + inv), r0_back = (1.0f - ior) / (1.0f + ior);
+                r0_front = r0_front * r0_front;
+                r0_back = r0_back * r0_back;
+                rf = f4{inv, r0_front, r0_back, ior};
             }
             out.rec_i[sl] = i4{m.x | (mat.type << 2) | (tex_type << 4), tex_id, m.z, m.w};
             out.rec_f[sl] = rf;
