@@ -654,6 +654,26 @@ RT_HD unsigned lds_node_words(int ref) {
 }
 RT_HD unsigned umin_(unsigned a, unsigned b) { return a < b ? a : b; }
 RT_HD unsigned umax_(unsigned a, unsigned b) { return a > b ? a : b; }
+RT_HD unsigned umed3_(unsigned a, unsigned b, unsigned c) { // the middle one of three
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+#else
+    return umax_(umin_(a, b), umin_(umax_(a, b), c));
+#endif
+}
+// Four keys in descending order with seven three-operand instructions: the first three are
+// sorted by min3 / med3 / max3, the fourth is placed among them (a compare-exchange network
+// takes ten two-operand ones).
+RT_HD void sort4_desc(unsigned k0, unsigned k1, unsigned k2, unsigned k3, unsigned &a0, unsigned &a1, unsigned &a2,
+                      unsigned &a3) {
+    const unsigned l = umin_(umin_(k0, k1), k2), h = umax_(umax_(k0, k1), k2), m = umed3_(k0, k1, k2);
+    a0 = umax_(h, k3);
+    a1 = umed3_(m, h, k3);
+    a2 = umed3_(l, m, k3);
+    a3 = umin_(l, k3);
+}
 
 // One inner node (requires tv.ref >= 0) of the 4-wide tree: tests the four child boxes, puts
 // the children that are hit on the stack, farthest first, and takes the nearest back.
@@ -691,10 +711,8 @@ RT_HD void trav_inner(Trav &tv, const f4 *nodes, float tmin, const ST &st, int r
     const unsigned k1 = h1 ? ((__builtin_bit_cast(unsigned, e1) & ~lo) | (__builtin_bit_cast(unsigned, q6.y) & lo)) : 0u;
     const unsigned k2 = h2 ? ((__builtin_bit_cast(unsigned, e2) & ~lo) | (__builtin_bit_cast(unsigned, q6.z) & lo)) : 0u;
     const unsigned k3 = h3 ? ((__builtin_bit_cast(unsigned, e3) & ~lo) | (__builtin_bit_cast(unsigned, q6.w) & lo)) : 0u;
-    const unsigned hi01 = umax_(k0, k1), lo01 = umin_(k0, k1), hi23 = umax_(k2, k3), lo23 = umin_(k2, k3);
-    const unsigned a0 = umax_(hi01, hi23), a3 = umin_(lo01, lo23);
-    const unsigned m1 = umin_(hi01, hi23), m2 = umax_(lo01, lo23);
-    const unsigned a1 = umax_(m1, m2), a2 = umin_(m1, m2);
+    unsigned a0, a1, a2, a3;
+    sort4_desc(k0, k1, k2, k3, a0, a1, a2, a3);
     const int n_hit = (int)h0 + (int)h1 + (int)h2 + (int)h3;
     const int sp = tv.sp, sd = st.stride();
     if (!SPILL || sp + 3 * sd < st.lds_end) {
