@@ -451,6 +451,12 @@ RT_HD void chain_hit_to_world(const DevScene &sc, int chain, f3 &p, f3 &n) {
 
 // ------------------------------------------------------------------------------------------
 // Traversal
+// Offset of a slot in 16-byte words: slot_f4 is 2 or 4, so a shift does (a 32-bit multiply
+// issues at quarter rate).  Builds without quads have 2-word slots only.
+RT_HD size_t slot_words(const DevScene &sc, int slot) {
+    return (size_t)(unsigned)slot << (RT_FEAT_QUAD ? (sc.slot_f4 >> 1) : 1);
+}
+
 struct TraceHit {
     float t;
     int slot; // -1: miss
@@ -663,6 +669,17 @@ RT_HD unsigned umed3_(unsigned a, unsigned b, unsigned c) { // the middle one of
     return umax_(umin_(a, b), umin_(umax_(a, b), c));
 #endif
 }
+// Stack key of a child: the high bits of its entry distance, the reference in the low bits.
+RT_HD unsigned key_of(unsigned hi_mask, float entry, float ref_bits_as_float) {
+    const unsigned e = __builtin_bit_cast(unsigned, entry), r = __builtin_bit_cast(unsigned, ref_bits_as_float);
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned k; // (the compiler keeps both masks in registers and spends an and + an and-or)
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(k) : "s"(hi_mask), "v"(e), "v"(r));
+    return k;
+#else
+    return (e & hi_mask) | (r & ~hi_mask);
+#endif
+}
 // Four keys in descending order with seven three-operand instructions: the first three are
 // sorted by min3 / med3 / max3, the fourth is placed among them (a compare-exchange network
 // takes ten two-operand ones).
@@ -705,12 +722,10 @@ RT_HD void trav_inner(Trav &tv, const f4 *nodes, float tmin, const ST &st, int r
     const bool h1 = box_hit(mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w), tv.br, tmin, tv.best_t, e1);
     const bool h2 = box_hit(mk(q3.x, q3.y, q3.z), mk(q3.w, q4.x, q4.y), tv.br, tmin, tv.best_t, e2);
     const bool h3 = box_hit(mk(q4.z, q4.w, q5.x), mk(q5.y, q5.z, q5.w), tv.br, tmin, tv.best_t, e3);
-    const unsigned lo = ref_bits >= 32 ? ~0u : (1u << ref_bits) - 1u;
-    // (e & ~lo) | (ref & lo): one v_bfi_b32 each
-    const unsigned k0 = h0 ? ((__builtin_bit_cast(unsigned, e0) & ~lo) | (__builtin_bit_cast(unsigned, q6.x) & lo)) : 0u;
-    const unsigned k1 = h1 ? ((__builtin_bit_cast(unsigned, e1) & ~lo) | (__builtin_bit_cast(unsigned, q6.y) & lo)) : 0u;
-    const unsigned k2 = h2 ? ((__builtin_bit_cast(unsigned, e2) & ~lo) | (__builtin_bit_cast(unsigned, q6.z) & lo)) : 0u;
-    const unsigned k3 = h3 ? ((__builtin_bit_cast(unsigned, e3) & ~lo) | (__builtin_bit_cast(unsigned, q6.w) & lo)) : 0u;
+    const unsigned hi = ref_bits >= 32 ? 0u : ~((1u << ref_bits) - 1u); // the bits of a key that hold the distance
+    // (the keys first, then the selects: a key built inside the conditional would become a branch)
+    const unsigned u0 = key_of(hi, e0, q6.x), u1 = key_of(hi, e1, q6.y), u2 = key_of(hi, e2, q6.z), u3 = key_of(hi, e3, q6.w);
+    const unsigned k0 = h0 ? u0 : 0u, k1 = h1 ? u1 : 0u, k2 = h2 ? u2 : 0u, k3 = h3 ? u3 : 0u;
     unsigned a0, a1, a2, a3;
     sort4_desc(k0, k1, k2, k3, a0, a1, a2, a3);
     const int n_hit = (int)h0 + (int)h1 + (int)h2 + (int)h3;
@@ -741,7 +756,7 @@ RT_HD void trav_test_leaf(Trav &tv, int leaf_ref, const DevScene &sc, const Scen
     int code = ~leaf_ref;
     int s = code >> 1;
     bool is_quad = RT_FEAT_QUAD && (code & 1) != 0;
-    const f4 *g = v.slots + (size_t)s * sc.slot_f4;
+    const f4 *g = v.slots + slot_words(sc, s);
     float t;
     bool h;
     // a primitive inside instance wrappers is tested in its object space (t is the same
@@ -824,7 +839,7 @@ RT_HD Surf surface_at(const DevScene &sc, const SceneView &vw, const Ray &r, Tra
     s.rec = m;
     f3 o = r.o, d = r.d;
     if (RT_FEAT_CHAIN && m.z >= 0) chain_ray_to_object(sc, m.z, o, d);
-    const f4 *g = vw.slots + (size_t)h.slot * sc.slot_f4;
+    const f4 *g = vw.slots + slot_words(sc, h.slot);
     f3 p = o + h.t * d; // ray.h:20
     f3 outward;
     s.u = 0.0f;
