@@ -245,6 +245,8 @@ inline Wide collapse_to_wide(const std::vector<f4> &bin) {
         w.nodes.resize(w.nodes.size() + 8, f4{0.0f, 0.0f, 0.0f, 0.0f});
         return w.n_nodes++;
     };
+    int null_ref = child_ref(0, 0); // the leftmost leaf
+    while (null_ref >= 0) null_ref = child_ref(null_ref, 0);
     todo.push_back({0, new_node(), 1});
     while (!todo.empty()) {
         const Item it = todo.back();
@@ -278,7 +280,10 @@ inline Wide collapse_to_wide(const std::vector<f4> &bin) {
                 fr.push_back({ref, 0, kl});
             }
         }
-        int refs[4] = {0, 0, 0, 0};
+        // An unused child names a real leaf: no finite ray enters its box, but a ray of NaNs
+        // passes every box test, and a reference to node 0 would send it round for ever (and its
+        // stack past its end); this way it ends in one more exact test that it fails.
+        int refs[4] = {null_ref, null_ref, null_ref, null_ref};
         float boxes[24];
         for (int k = 0; k < 4; k++) {
             if (k < n) {

@@ -343,3 +343,34 @@ def test_kernel_logic_on_random_scenes(seed):
     want, st = osc.render(cam, 2, sampler=O.SAMPLER_CB, trace_mode=O.TRACE_REFERENCE, seed=seed)
     assert n_rays == st.rays
     assert np.allclose(acc, want, rtol=2e-6, atol=1e-7)
+
+
+def test_kernel_logic_ends_on_rays_that_are_not_numbers():
+    """The traversal code compiled for the host: NaN / infinite / zero / huge rays end (a NaN
+    passes every box test and walks the whole tree) with the oracle's answer, in every stack
+    variant.  An unused child slot therefore names a leaf, never a node."""
+    from tests import sim_lib
+    arrays, _, _ = load_scene("bouncing_spheres")
+    nan, inf = np.nan, np.inf
+    cases = [((nan, 0, 0), (0, 0, -1)), ((0, 1, 5), (nan, 0, -1)), ((0, 1, 5), (nan, nan, nan)),
+             ((inf, 1, 5), (0, 0, -1)), ((0, 1, 5), (0, inf, -1)), ((0, 1, 5), (0, 0, 0)),
+             ((0, 1, 5), (0, 0, -1e38)), ((0, 1, 5), (1e-42, 0, -1e-42)), ((0, 1, 5), (0, 0, -1)),
+             ((-inf, inf, nan), (inf, -inf, nan)), ((3e38, 3e38, 3e38), (-1, -1, -1))]
+    rays = np.zeros(len(cases), abi.RAY_DT)
+    for i, (o, d) in enumerate(cases):
+        rays["orig"][i] = o
+        rays["dir"][i] = d
+    osc = O.OracleScene(arrays)
+    with np.errstate(all="ignore"):
+        oh, _ = osc.trace(rays, 0.001, np.inf, O.TRACE_REFERENCE)
+    assert oh["prim"][8] >= 0 and (oh["prim"][:3] == -1).all()
+    sim = sim_lib.SimScene(arrays)
+    try:
+        for mode in (0, 1, 2):
+            sim_lib.set_stack_mode(mode)
+            got = sim.trace(rays, 0.001, np.inf)
+            hits = got[0] if isinstance(got, tuple) else got
+            assert np.array_equal(hits["prim"], oh["prim"]), mode
+            assert ((hits["t"] == oh["t"]) | (hits["prim"] < 0)).all(), mode
+    finally:
+        sim_lib.set_stack_mode(0)

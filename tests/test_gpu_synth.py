@@ -268,6 +268,7 @@ def _tree_stats(nodes):
             centre, half = nd[6 * k:6 * k + 3], nd[6 * k + 3:6 * k + 6]
             if k >= refs[i, 4]:
                 assert (half < 0).all(), "an unused child must have an inverted box"
+                assert refs[i, k] < 0, "an unused child must name a leaf (never a node: a ray of NaNs would loop)"
                 continue
             lo, hi = centre - half, centre + half
             if box is not None and (np.any(lo < box[0] - 1e-3 * (1 + np.abs(box[0]))) or

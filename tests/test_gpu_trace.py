@@ -178,3 +178,39 @@ def test_edge_cases():
     assert sc.trace(rays, 0.001, np.inf)["t"][0] == 10.0
     assert sc.trace(rays, 0.001, 10.0)["prim"][0] == -1
     sc.close()
+
+
+def test_rays_that_are_not_numbers_end():
+    """NaN / infinite / zero / huge rays: every traversal ends (a NaN passes every box test, so
+    such a ray walks the whole tree and fails every exact test) and reports what the oracle's
+    scan reports; on the scene held in LDS, read from HBM, with a short LDS stack, through both
+    batch kernels."""
+    B = _binding()
+    arrays, cam, _ = load_scene("bouncing_spheres")
+    nan, inf = np.nan, np.inf
+    cases = [((nan, 0, 0), (0, 0, -1)), ((0, 1, 5), (nan, 0, -1)), ((0, 1, 5), (nan, nan, nan)),
+             ((inf, 1, 5), (0, 0, -1)), ((0, 1, 5), (0, inf, -1)), ((0, 1, 5), (0, 0, 0)),
+             ((0, 1, 5), (0, 0, -1e38)), ((0, 1, 5), (1e-42, 0, -1e-42)), ((0, 1, 5), (0, 0, -1)),
+             ((-inf, inf, nan), (inf, -inf, nan)), ((3e38, 3e38, 3e38), (-1, -1, -1))]
+    rays = np.zeros(64 * len(cases), abi.RAY_DT)  # whole waves of each, so that none hides behind a neighbour
+    for i, (o, d) in enumerate(cases):
+        rays["orig"][i::len(cases)] = o
+        rays["dir"][i::len(cases)] = d
+    osc = O.OracleScene(arrays)
+    with np.errstate(all="ignore"):
+        oh, _ = osc.trace(rays, 0.001, np.inf, O.TRACE_REFERENCE)
+    assert (oh["prim"][:len(cases)][[0, 1, 2]] == -1).all() and oh["prim"][8] >= 0
+    for flags, env in ((0, {}), (abi.RT_SCENE_FORCE_GLOBAL, {}), (abi.RT_SCENE_FORCE_GLOBAL, {"RT_AMD_LDS_STACK": "4"})):
+        for k, v in env.items():
+            os.environ[k] = v
+        try:
+            sc = B.Scene(arrays, flags=flags)
+        finally:
+            for k in env:
+                del os.environ[k]
+        for sched in (False, True):
+            hits = sc.trace(rays, sched=sched)
+            assert np.array_equal(hits["prim"], oh["prim"]), (flags, env, sched)
+            same_t = (hits["t"] == oh["t"]) | (hits["prim"] < 0)
+            assert same_t.all(), (flags, env, sched)
+        sc.close()
