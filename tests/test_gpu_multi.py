@@ -80,3 +80,36 @@ def test_dropin_camera_splits_over_the_listed_devices(tmp_path):
         pngs.append(np.asarray(Image.open(png).convert("RGB")).astype(np.int32))
     d = np.abs(pngs[0] - pngs[1])
     assert d.max() <= 1 and (d > 0).mean() < 1e-3
+
+
+def test_bench_under_the_launcher_reduces_over_rccl():
+    """bench.py started the way the driver starts it for several GPUs (torch.distributed.run,
+    backend nccl = RCCL), here with the one rank this box has: the process group, the
+    asynchronous reduce of the accumulation images and the max-over-ranks timing all run; the
+    line must name one GPU and a throughput close to the launcher-less run's."""
+    import json
+    import sys
+
+    from raytracing_amd.spp_split import free_port
+    common = ["--steps", "3", "--warmup", "1", "--repeats", "2", "--no-cpu-baseline", "--no-configs"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    launched = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                               "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+                               os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common,
+                              capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert launched.returncode == 0, launched.stderr[-2000:]
+    line = json.loads([ln for ln in launched.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["scaling"] == "weak" and line["value"] > 0
+    assert "RCCL" in line["config"]["parallelism"] or line["config"]["parallelism"] == "single GPU"
+    plain = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common,
+                           capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    ref = json.loads([ln for ln in plain.stdout.splitlines() if ln.startswith("{")][-1])
+    assert ref["config"]["spp_per_gpu_per_step"] == line["config"]["spp_per_gpu_per_step"]
+    assert 0.5 < line["value"] / ref["value"] < 2.0
+    # two ranks on this one-GPU box: refused, not mislabelled
+    two = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common,
+                         capture_output=True, text=True, timeout=120, cwd=ROOT)
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert two.returncode == 2 and "refusing" in two.stderr
