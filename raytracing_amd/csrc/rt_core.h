@@ -144,6 +144,7 @@ struct DevScene {
     const rt_texture *textures;
     const f4 *xf;
     const int *chain_first; // chain c covers ops [chain_first[c], chain_first[c+1])
+    const f4 *scan;         // linear scenes: RT_SCAN_F4 words per slot, what the scan needs of it (trace_linear)
     const DevPerlin *perlins;
     const rt_image *images;
     const uint8_t *texels;
@@ -338,6 +339,35 @@ RT_HD bool quad_test_straight(f4 g0, f4 g1, f4 g2, f4 g3, f3 o, f3 d, float tmin
     return hit;
 }
 
+// A quad whose normal lies along axis K and whose u and v lie along the two other axes I = K + 1,
+// J = K + 2 (mod 3), u along I and v along J (the host swaps u and v where it is the other way
+// round, which negates n, D and w and exchanges alpha and beta: the same t and the same verdict).
+// The terms of quad.h:32-62 that multiply a zero component are zeros, and adding or subtracting
+// a zero changes nothing, so what is left gives the same bits:
+//   dot(n, x) = n_K x_K;   alpha = w_K (planar_I v_J);   beta = w_K (u_I planar_J).
+// 27 instructions instead of 75.
+template <int K> RT_HD float axis_of(f3 v) { return K == 0 ? v.x : K == 1 ? v.y : v.z; }
+template <int K>
+RT_HD bool quad_test_axis(float nk, float D, float qi, float qj, float wk, float ui, float vj, f3 o, f3 d, float tmin,
+                          float tmax, float &t_out) {
+    constexpr int I = (K + 1) % 3, J = (K + 2) % 3;
+    const float denominator = nk * axis_of<K>(d);
+    const float t = (D - nk * axis_of<K>(o)) / denominator;
+    const float planar_i = (axis_of<I>(o) + t * axis_of<I>(d)) - qi;
+    const float planar_j = (axis_of<J>(o) + t * axis_of<J>(d)) - qj;
+    const float alpha = wk * (planar_i * vj);
+    const float beta = wk * (ui * planar_j);
+    t_out = t;
+    return !(fabsf(denominator) < 1e-8f) & (tmin <= t) & (t <= tmax) & (0.0f <= alpha) & (alpha <= 1.0f) &
+           (0.0f <= beta) & (beta <= 1.0f);
+}
+// Scan record of a slot, RT_SCAN_F4 x 16 bytes: {kind, chain, n_K, D} {Q_I, Q_J, w_K, u_I} {v_J, -, -, -};
+// kind: RT_SCAN_SPHERE / RT_SCAN_QUAD (tested from the slot itself) or RT_SCAN_AXIS + K.
+#define RT_SCAN_F4 3
+#define RT_SCAN_SPHERE 0
+#define RT_SCAN_QUAD 1
+#define RT_SCAN_AXIS 2
+
 // ------------------------------------------------------------------------------------------
 // Instance wrappers (hittable.h:51-344), applied to the ray at run time exactly
 // as the reference does; used by the linear traversal, where it costs one ray
@@ -477,36 +507,48 @@ RT_HD TraceHit trace_linear(const DevScene &sc, const SceneView &v, const Ray &r
     float dd = len2(d);
     const int stride = sc.slot_f4;
     const uf4_ptr u_slots = (uf4_ptr)sc.slots;
-    const ui4_ptr u_rec = (ui4_ptr)sc.rec_i;
+    const uf4_ptr u_scan = (uf4_ptr)sc.scan;
+    if (sc.n_slots <= 0) return best;
+    // The scan record of slot s + 1 is requested before slot s is tested: a scalar load takes a
+    // few hundred cycles and an axis-aligned quad is tested in under thirty instructions.
+    f4 r0 = u_scan[0], r1 = u_scan[1], r2 = u_scan[2];
     for (int s = 0; s < sc.n_slots; s++) {
-        const i4 m = u_rec[s];
-        if (m.z != cur_chain) {
-            cur_chain = m.z;
+        const uf4_ptr nx = u_scan + (size_t)(s + 1 < sc.n_slots ? s + 1 : s) * RT_SCAN_F4;
+        const f4 n0 = nx[0], n1 = nx[1], n2 = nx[2];
+        const int kind = __builtin_bit_cast(int, r0.x), chain = __builtin_bit_cast(int, r0.y);
+        if (chain != cur_chain) {
+            cur_chain = chain;
             o = r.o;
             d = r.d;
             if (RT_FEAT_CHAIN && cur_chain >= 0)
                 chain_ray_to_object_p((uf4_ptr)sc.xf, (uint_ptr)sc.chain_first, cur_chain, o, d);
             dd = len2(d);
         }
-        const uf4_ptr g = u_slots + (size_t)s * stride;
         float t;
         bool h;
-        if (!RT_FEAT_QUAD || RT_KIND_PRIM(m.x) == RT_PRIM_SPHERE) {
+        if (!RT_FEAT_QUAD || kind == RT_SCAN_SPHERE) {
+            const uf4_ptr g = u_slots + (size_t)s * stride;
             RT_COUNT(sph);
             h = sphere_test(g[0], g[1], o, d, dd, r.tm, tmin, best.t, t);
             if constexpr (COUNT) cn.sphh += h ? 1 : 0;
         } else {
             RT_COUNT(quad);
-#if defined(RT_SCAN_BRANCHY)
-            h = quad_test(g[0], g[1], g[2], g[3], o, d, tmin, best.t, t);
-#else
-            h = quad_test_straight(g[0], g[1], g[2], g[3], o, d, tmin, best.t, t);
-#endif
+            if (kind == RT_SCAN_AXIS + 0) {
+                h = quad_test_axis<0>(r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, o, d, tmin, best.t, t);
+            } else if (kind == RT_SCAN_AXIS + 1) {
+                h = quad_test_axis<1>(r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, o, d, tmin, best.t, t);
+            } else if (kind == RT_SCAN_AXIS + 2) {
+                h = quad_test_axis<2>(r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, o, d, tmin, best.t, t);
+            } else {
+                const uf4_ptr g = u_slots + (size_t)s * stride;
+                h = quad_test_straight(g[0], g[1], g[2], g[3], o, d, tmin, best.t, t);
+            }
         }
         if (h) {
             best.t = t;
             best.slot = s;
         }
+        r0 = n0, r1 = n1, r2 = n2;
     }
     return best;
 }

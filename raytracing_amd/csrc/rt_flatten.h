@@ -93,6 +93,44 @@ void quad_slot(f3 Q, f3 u, f3 v, f4 out[4]) {
     out[3] = f4{u.z, v.x, v.y, v.z};
 }
 
+// Scan record of a slot (rt_core.h: RT_SCAN_*).  A quad whose normal, u and v each lie along a
+// coordinate axis (the sides of box(), walls) gets the seven numbers quad_test_axis needs, in
+// the canonical orientation (u along axis K + 1, v along K + 2; if the quad has them the other
+// way round, u and v change places, which negates n, D and w).
+inline void scan_record(int type, int chain, const f4 *g, f4 out[3]) {
+    auto as_f = [](int v) { return __builtin_bit_cast(float, v); };
+    out[0] = f4{as_f(type == RT_PRIM_SPHERE ? RT_SCAN_SPHERE : RT_SCAN_QUAD), as_f(chain), 0.0f, 0.0f};
+    out[1] = out[2] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (type == RT_PRIM_SPHERE) return;
+    const float n[3] = {g[0].x, g[0].y, g[0].z}, w[3] = {g[1].w, g[2].x, g[2].y}, Q[3] = {g[1].x, g[1].y, g[1].z};
+    const float u[3] = {g[2].z, g[2].w, g[3].x}, v[3] = {g[3].y, g[3].z, g[3].w};
+    const float D = g[0].w;
+    for (int c = 0; c < 3; c++)
+        if (!std::isfinite(n[c]) || !std::isfinite(w[c]) || !std::isfinite(u[c]) || !std::isfinite(v[c]) ||
+            !std::isfinite(Q[c]) || !std::isfinite(D))
+            return;
+    for (int k = 0; k < 3; k++) {
+        const int i = (k + 1) % 3, j = (k + 2) % 3;
+        if (n[k] == 0.0f || n[i] != 0.0f || n[j] != 0.0f) continue;
+        if (w[k] == 0.0f || w[i] != 0.0f || w[j] != 0.0f) continue;
+        if (u[k] != 0.0f || v[k] != 0.0f) continue;
+        const bool straight = u[i] != 0.0f && u[j] == 0.0f && v[i] == 0.0f && v[j] != 0.0f;
+        const bool swapped = u[i] == 0.0f && u[j] != 0.0f && v[i] != 0.0f && v[j] == 0.0f;
+        if (!straight && !swapped) continue;
+        out[0].x = as_f(RT_SCAN_AXIS + k);
+        if (straight) {
+            out[0].z = n[k], out[0].w = D;
+            out[1] = f4{Q[i], Q[j], w[k], u[i]};
+            out[2].x = v[j];
+        } else {
+            out[0].z = -n[k], out[0].w = -D;
+            out[1] = f4{Q[i], Q[j], -w[k], v[i]};
+            out[2].x = u[j];
+        }
+        return;
+    }
+}
+
 struct Box3 {
     float lo[3], hi[3];
     void reset() {
@@ -600,6 +638,7 @@ struct HostScene {
     std::vector<rt_texture> textures; // textures reachable from non-solid material textures
     std::vector<f4> nodes;       // 8 per node of the 4-wide tree (empty: linear scan)
     std::vector<f4> xf;          // RT_XF_F4 per wrapper op, packed chain by chain
+    std::vector<f4> scan;        // linear scenes: RT_SCAN_F4 per slot (rt_core.h trace_linear)
     std::vector<rtc::DevPerlin> perlins;
     std::vector<int> chain_first; // n_chains + 1
     int slot_f4 = 2;
@@ -788,6 +827,10 @@ inline int flatten_scene(const rt_scene_desc *d, uint32_t flags, HostScene &out,
                 rf = f4{inv, r0_front, r0_back, ior};
             }
             out.rec_i[sl] = i4{m.x | (mat.type << 2) | (tex_type << 4), tex_id, m.z, m.w};
+            if (linear) {
+                if (sl == 0) out.scan.resize((size_t)n * RT_SCAN_F4);
+                scan_record(m.x, m.z, &slots[(size_t)sl * slot_f4], &out.scan[(size_t)sl * RT_SCAN_F4]);
+            }
             out.rec_f[sl] = rf;
         }
     }

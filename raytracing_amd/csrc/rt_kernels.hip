@@ -39,8 +39,12 @@ namespace {
 // ------------------------------------------------------------------------------------------
 // One whole ray per lane per iteration.  Linear scenes: every lane walks the same
 // primitive list, so the traversal itself is divergence-free.
-template <int TRAV, bool LDS_SCENE, bool COUNT, bool RING>
-__global__ void __launch_bounds__(RT_MEGA_MAX_THREADS, RT_MEGA_WAVES_PER_SIMD)
+// WPS: waves per SIMD the kernel is compiled for.  A scan of many quads does so little arithmetic
+// per scalar load and branch that it is bound by each wave's own instruction latency: the build
+// for 8 waves per SIMD (64 registers; some shading code spills) is 1.2-1.3x faster there, and
+// slower on scenes of a few textured spheres, where the spills cost more than the occupancy gives.
+template <int TRAV, bool LDS_SCENE, bool COUNT, bool RING, int WPS = RT_MEGA_WAVES_PER_SIMD>
+__global__ void __launch_bounds__(RT_MEGA_MAX_THREADS, WPS)
 render_mega(DevScene sc, DevCamera cam, RenderParams rp) {
     extern __shared__ f4 smem[];
     __shared__ BlockPool block_pool;
@@ -672,6 +676,9 @@ static hipError_t launch_mega_tcr(const DevScene &sc, const DevCamera &cam, cons
     if (rp.counters)
         hipLaunchKernelGGL((render_mega<TRAV, LDS_SCENE, true, RING>), dim3(lg.grid), dim3(lg.block), lg.lds_bytes,
                            stream, sc, cam, rp);
+    else if (TRAV == TRAV_LINEAR && lg.dense)
+        hipLaunchKernelGGL((render_mega<TRAV, LDS_SCENE, false, RING, TRAV == TRAV_LINEAR ? 8 : RT_MEGA_WAVES_PER_SIMD>),
+                           dim3(lg.grid), dim3(lg.block), lg.lds_bytes, stream, sc, cam, rp);
     else
         hipLaunchKernelGGL((render_mega<TRAV, LDS_SCENE, false, RING>), dim3(lg.grid), dim3(lg.block), lg.lds_bytes,
                            stream, sc, cam, rp);
@@ -733,6 +740,15 @@ hipError_t RT_LAUNCH_NAME(set_mega_lds_limit)(int bytes) {
     if (e == hipSuccess)                                                                                     \
         e = hipFuncSetAttribute((const void *)render_mega<TR, L, C, true>,                                   \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+#define RT_SET8(L, R)                                                                                        \
+    if (e == hipSuccess)                                                                                     \
+        e = hipFuncSetAttribute((const void *)render_mega<TRAV_LINEAR, L, false, R, 8>,                      \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    RT_SET8(true, true)
+    RT_SET8(true, false)
+    RT_SET8(false, true)
+    RT_SET8(false, false)
+#undef RT_SET8
     RT_SET(TRAV_LINEAR, true, true)
     RT_SET(TRAV_LINEAR, true, false)
     RT_SET(TRAV_LINEAR, false, true)

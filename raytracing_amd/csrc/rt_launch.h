@@ -72,6 +72,9 @@ struct LaunchGeom {
     // by all lanes at once when the unit is taken; idle lanes then only fetch theirs)
     bool ring = false;
     int ring_f4 = 0; // offset of the rings in dynamic LDS, in 16-byte words
+    // linear scenes that are mostly scan: the kernel built for 8 waves per SIMD.  Pipelined launches
+    // keep one workgroup per CU each (two launches share a CU); a launch on its own starts two.
+    bool dense = false;
 };
 #define RT_RING_F4_PER_WAVE (3 * 64) // {origin, time} {direction, sampler state} {pixel, local sample, -, -}
 

@@ -44,6 +44,7 @@ void *sim_scene_create(const rt_scene_desc *d, uint32_t flags) {
     dv.nodes = s->hs.nodes.data();
     dv.xf = s->hs.xf.data();
     dv.chain_first = s->hs.chain_first.data();
+    dv.scan = s->hs.scan.data();
     dv.perlins = s->hs.perlins.data();
     dv.n_perlins = (int)s->hs.perlins.size();
     dv.images = s->imgs.data();
