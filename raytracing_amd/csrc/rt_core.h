@@ -361,8 +361,10 @@ RT_HD bool quad_test_axis(float nk, float D, float qi, float qj, float wk, float
     return !(fabsf(denominator) < 1e-8f) & (tmin <= t) & (t <= tmax) & (0.0f <= alpha) & (alpha <= 1.0f) &
            (0.0f <= beta) & (beta <= 1.0f);
 }
-// Scan record of a slot, RT_SCAN_F4 x 16 bytes: {kind, chain, n_K, D} {Q_I, Q_J, w_K, u_I} {v_J, -, -, -};
-// kind: RT_SCAN_SPHERE / RT_SCAN_QUAD (tested from the slot itself) or RT_SCAN_AXIS + K.
+// Scan record of a slot, RT_SCAN_F4 x 16 bytes, by kind:
+//   RT_SCAN_AXIS + K: {kind, chain, n_K, D} {Q_I, Q_J, w_K, u_I} {v_J, -, -, -}
+//   RT_SCAN_SPHERE:   {kind, chain, c.x, c.y} {c.z, radius, cv.x, cv.y} {cv.z, -, -, -}
+//   RT_SCAN_QUAD:     {kind, chain, -, -} ... (tested from the slot itself)
 #define RT_SCAN_F4 3
 #define RT_SCAN_SPHERE 0
 #define RT_SCAN_QUAD 1
@@ -527,9 +529,8 @@ RT_HD TraceHit trace_linear(const DevScene &sc, const SceneView &v, const Ray &r
         float t;
         bool h;
         if (!RT_FEAT_QUAD || kind == RT_SCAN_SPHERE) {
-            const uf4_ptr g = u_slots + (size_t)s * stride;
             RT_COUNT(sph);
-            h = sphere_test(g[0], g[1], o, d, dd, r.tm, tmin, best.t, t);
+            h = sphere_test(f4{r0.z, r0.w, r1.x, r1.y}, f4{r1.z, r1.w, r2.x, 0.0f}, o, d, dd, r.tm, tmin, best.t, t);
             if constexpr (COUNT) cn.sphh += h ? 1 : 0;
         } else {
             RT_COUNT(quad);

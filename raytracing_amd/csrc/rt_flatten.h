@@ -101,7 +101,12 @@ inline void scan_record(int type, int chain, const f4 *g, f4 out[3]) {
     auto as_f = [](int v) { return __builtin_bit_cast(float, v); };
     out[0] = f4{as_f(type == RT_PRIM_SPHERE ? RT_SCAN_SPHERE : RT_SCAN_QUAD), as_f(chain), 0.0f, 0.0f};
     out[1] = out[2] = f4{0.0f, 0.0f, 0.0f, 0.0f};
-    if (type == RT_PRIM_SPHERE) return;
+    if (type == RT_PRIM_SPHERE) { // centre, radius, centre motion: what sphere_test reads of the slot
+        out[0].z = g[0].x, out[0].w = g[0].y;
+        out[1] = f4{g[0].z, g[0].w, g[1].x, g[1].y};
+        out[2].x = g[1].z;
+        return;
+    }
     const float n[3] = {g[0].x, g[0].y, g[0].z}, w[3] = {g[1].w, g[2].x, g[2].y}, Q[3] = {g[1].x, g[1].y, g[1].z};
     const float u[3] = {g[2].z, g[2].w, g[3].x}, v[3] = {g[3].y, g[3].z, g[3].w};
     const float D = g[0].w;
