@@ -374,3 +374,60 @@ def test_kernel_logic_ends_on_rays_that_are_not_numbers():
             assert ((hits["t"] == oh["t"]) | (hits["prim"] < 0)).all(), mode
     finally:
         sim_lib.set_stack_mode(0)
+
+
+def axis_aligned_quads_scene(seed=3, n=30):
+    """Quads along the coordinate axes in every orientation: normal along x, y or z, u and v in
+    either order and with either sign, some inside wrappers, a few general quads and spheres in
+    between.  The scan tests the axis-aligned ones with a shortened formula (quad_test_axis)."""
+    rng = np.random.default_rng(seed)
+    prims = np.zeros(n, abi.PRIM_DT)
+    prims["xform"] = -1
+    ops, chains = [], []
+    for i in range(n):
+        q = rng.uniform(-3, 3, 3)
+        if i % 7 == 5:
+            prims[i]["type"] = abi.RT_PRIM_SPHERE
+            prims[i]["a"], prims[i]["c"] = q, (rng.uniform(0.3, 0.9), 0, 0)
+            continue
+        prims[i]["type"] = abi.RT_PRIM_QUAD
+        u, v = np.zeros(3), np.zeros(3)
+        if i % 7 == 6:  # a general one
+            u, v = rng.uniform(-2, 2, 3), rng.uniform(-2, 2, 3)
+        else:
+            k = i % 3
+            a, b = ((k + 1) % 3, (k + 2) % 3) if (i // 3) % 2 == 0 else ((k + 2) % 3, (k + 1) % 3)
+            u[a] = rng.uniform(0.5, 3) * rng.choice([-1, 1])
+            v[b] = rng.uniform(0.5, 3) * rng.choice([-1, 1])
+        prims[i]["a"], prims[i]["b"], prims[i]["c"] = q, u, v
+        if i % 4 == 1:
+            first = len(ops)
+            ops.append((abi.RT_XF_ROTATE_Y, (rng.uniform(-180, 180), 0, 0)))
+            ops.append((abi.RT_XF_TRANSLATE, tuple(rng.uniform(-2, 2, 3))))
+            chains.append((first, 2))
+            prims[i]["xform"] = len(chains) - 1
+    mats = np.zeros(1, abi.MATERIAL_DT)
+    tex = np.zeros(1, abi.TEXTURE_DT)
+    return abi.SceneArrays(prims=prims, materials=mats, textures=tex,
+                           xform_ops=np.array(ops, abi.XFORM_OP_DT), chains=np.array(chains, abi.CHAIN_DT))
+
+
+def axis_aligned_rays(n, seed=9):
+    rng = np.random.default_rng(seed)
+    rays = np.zeros(n, abi.RAY_DT)
+    o = rng.normal(size=(n, 3))
+    o *= rng.uniform(6, 12, size=(n, 1)) / np.linalg.norm(o, axis=1, keepdims=True)
+    d = rng.uniform(-4, 4, (n, 3)) - o
+    d[::5, 0] = 0.0   # rays parallel to a coordinate plane: zero denominators for some quads
+    d[1::7] = np.sign(d[1::7]) * np.abs(d[1::7]).max(axis=1, keepdims=True) * (np.abs(d[1::7]) == np.abs(d[1::7]).max(axis=1, keepdims=True))
+    rays["orig"], rays["dir"] = o, d
+    return rays
+
+
+def test_kernel_logic_axis_aligned_quads_in_a_scan():
+    arrays = axis_aligned_quads_scene()
+    rays = axis_aligned_rays(40_000)
+    ref, _ = O.OracleScene(arrays).trace(rays, 0.001, np.inf, O.TRACE_REFERENCE)
+    assert (ref["prim"] >= 0).mean() > 0.2 and len(set(ref["prim"].tolist())) > 20
+    lin, _, _ = S.SimScene(arrays).trace(rays)
+    assert lin.tobytes() == ref.tobytes()

@@ -214,3 +214,24 @@ def test_rays_that_are_not_numbers_end():
             same_t = (hits["t"] == oh["t"]) | (hits["prim"] < 0)
             assert same_t.all(), (flags, env, sched)
         sc.close()
+
+
+def test_axis_aligned_quads_in_a_scan():
+    """The scan's shortened test for quads along the coordinate axes (every orientation, both
+    orders and signs of u and v, some inside wrappers) next to general quads and spheres:
+    records equal to the oracle's (t, p, normal, and a quad's u and v bit for bit), through both
+    batch kernels."""
+    from tests.test_abi_and_host import axis_aligned_quads_scene, axis_aligned_rays
+    B = _binding()
+    arrays = axis_aligned_quads_scene()
+    rays = axis_aligned_rays(200_000)
+    ref, _ = O.OracleScene(arrays).trace(rays, 0.001, np.inf, O.TRACE_REFERENCE)
+    sc = B.Scene(arrays)
+    assert sc.info().n_nodes == 0  # scanned, not a tree
+    for sched in (False, True):
+        hits = sc.trace(rays, sched=sched)
+        _check_records(hits, ref)
+        quads = (ref["prim"] >= 0) & (arrays.prims["type"][np.maximum(ref["prim"], 0)] == abi.RT_PRIM_QUAD)
+        assert quads.sum() > 10_000  # (u, v of a quad are alpha and beta: exact; a sphere's go through acos / atan2)
+        assert np.array_equal(hits["u"][quads], ref["u"][quads]) and np.array_equal(hits["v"][quads], ref["v"][quads])
+    sc.close()
