@@ -745,7 +745,7 @@ static int impl_rt_render_device(rt_scene *s, const rt_camera_desc *cam, const r
     const bool pipelined = !wavefront && !stats && !(opts->flags & RT_RENDER_NO_OVERLAP) && tn.pipeline != 0;
     // the 8-waves-per-SIMD scan kernel: two pipelined launches share a CU with a workgroup each;
     // launches that run one at a time start two workgroups per CU themselves
-    if (lg.dense && !pipelined && !count) lg.grid *= 2;
+    if (lg.dense && !pipelined && !count && !wavefront) lg.grid *= 2;
     float mega_ms = 0.0f;
     for (int done = 0; done < opts->sample_count; done += chunk) {
         int sc_n = std::min(chunk, opts->sample_count - done);
