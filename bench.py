@@ -257,7 +257,7 @@ def load_workload(name, width=0):
     return arrays, cam
 
 
-# the other workloads BASELINE.json names, as one GPU runs them: (scene, spp per step, steps, CPU sample in paths)
+# the reference's other benchmark configurations, as one GPU runs them: (scene, spp per step, steps, CPU sample in paths)
 OTHER_CONFIGS = [
     ("config2", "checkered_spheres", 100, 10, 4.5e6), ("config2", "perlin_spheres", 100, 10, 1.8e6),
     ("config3", "earth", 100, 10, 9e6), ("config3", "quads", 100, 10, 6.4e6), ("config3", "simple_light", 100, 10, 3.6e6),
@@ -293,11 +293,11 @@ def run_other_configs(args, dev_index):
             if name == "synth1m":
                 # the reference has no such scene and its bvh_node constructor alone takes 10 s on a
                 # million primitives; the figure measured with the reference's classes in the
-                # authoring container (BASELINE.md) is quoted instead of a timing here
+                # authoring container is quoted instead of a timing here
                 entry["cpu_baseline"] = {"value": None, "unit": "Mpaths/s", "cores": 1, "kind": "reference",
                                          "sample": "not timed in this run",
                                          "measured_elsewhere": {"value": 0.070, "mrays_per_s": 0.43,
-                                                                "sample": "480x270 at 1 spp, 1 thread, authoring container (BASELINE.md)"}}
+                                                                "sample": "480x270 at 1 spp, 1 thread, measured in the authoring container"}}
             else:
                 entry["cpu_baseline"] = cpu_baseline(name, cpu_paths, port_too=False)
                 print(f"[bench] {name}: CPU reference {entry['cpu_baseline']['value']:.3f} Mpaths/s", file=sys.stderr, flush=True)
