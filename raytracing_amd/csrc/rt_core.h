@@ -673,7 +673,7 @@ RT_HD void trav_begin(Trav &tv, const Ray &r, float tmax) {
 template <typename T> RT_HD int stack_entry_ref(T e, int ref_bits) {
     if (sizeof(T) == 2) return (int)e;
     const int sh = 32 - ref_bits;
-    return ((int)e << sh) >> sh;
+    return (int)((unsigned)e << sh) >> sh; // (sign extension of the low ref_bits bits)
 }
 template <class ST, bool SPILL> RT_HD void trav_pop(Trav &tv, const ST &st, int ref_bits) {
     typedef typename ST::elem T;

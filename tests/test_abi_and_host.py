@@ -431,3 +431,26 @@ def test_kernel_logic_axis_aligned_quads_in_a_scan():
     assert (ref["prim"] >= 0).mean() > 0.2 and len(set(ref["prim"].tolist())) > 20
     lin, _, _ = S.SimScene(arrays).trace(rays)
     assert lin.tobytes() == ref.tobytes()
+
+
+def test_host_logic_under_address_and_ub_sanitizers(tmp_path):
+    """The host-side code the library shares with the kernels (flattening, the wide tree, the
+    traversal and intersection logic, the scene-file reader), compiled with -fsanitize=address,
+    undefined and run over every golden scene in every traversal and stack variant: no report."""
+    import glob
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    src = os.path.join(ROOT, "tests", "sanitize", "host_logic_sanitize.cpp")
+    exe = str(tmp_path / "host_logic_sanitize")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
+                    "-ffp-contract=off", "-pthread", "-I" + os.path.join(ROOT, "include"),
+                    "-I" + os.path.join(ROOT, "raytracing_amd", "csrc"), "-o", exe, src], check=True)
+    scenes = sorted(glob.glob(os.path.join(GOLDEN, "*.rtscene")))
+    run = subprocess.run([exe] + scenes, capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1"))
+    out = run.stdout + run.stderr
+    assert run.returncode == 0, out[-3000:]
+    assert "runtime error" not in out and "AddressSanitizer" not in out and "LeakSanitizer" not in out, out[-3000:]
+    assert out.count("flags") >= 3 * len(scenes) - 1

@@ -150,6 +150,46 @@ def test_host_side_materials_and_textures(tmp_path):
     assert r.returncode == 0, r.stdout.decode() + r.stderr.decode()
 
 
+def test_image_decoder_survives_damaged_files_under_sanitizers(tmp_path):
+    """The drop-in's image reader (its own JPEG decoder, PPM and raw dumps) takes files from
+    users: truncated, bit-flipped and spliced copies of the JPEG fixtures must end in a decoded
+    image or a refusal, never in a report of -fsanitize=address,undefined."""
+    import glob
+    import random
+    exe = str(tmp_path / "rt_image_sanitized")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
+                    "-I" + os.path.join(ROOT, "raytracing_amd", "dropin"), "-I" + os.path.join(ROOT, "raytracing_amd", "csrc"),
+                    "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "image_dump.cpp"), "-o", exe,
+                    "-L" + os.path.join(ROOT, "raytracing_amd", "lib"), "-lrt_amd",
+                    "-Wl,-rpath," + os.path.join(ROOT, "raytracing_amd", "lib")], check=True)
+    rng = random.Random(5)
+    out = str(tmp_path / "out.rtimg")
+    bad = str(tmp_path / "damaged.jpg")
+    runs = 0
+    for path in sorted(glob.glob(os.path.join(GOLDEN, "jpeg", "*.jpg"))):
+        data = open(path, "rb").read()
+        for k in range(10):
+            b = bytearray(data)
+            if k % 4 == 0:
+                b = b[:rng.randrange(2, len(b))]
+            elif k % 4 == 1:
+                for _ in range(rng.randrange(1, 6)):
+                    b[rng.randrange(0, min(len(b), 700))] = rng.randrange(256)
+            elif k % 4 == 2:
+                for _ in range(rng.randrange(1, 30)):
+                    b[rng.randrange(0, len(b))] = rng.randrange(256)
+            else:
+                i, j, n = rng.randrange(0, len(b)), rng.randrange(0, len(b)), rng.randrange(1, 200)
+                b[i:i + n] = b[j:j + n]
+            with open(bad, "wb") as f:
+                f.write(bytes(b))
+            r = subprocess.run([exe, bad, out], capture_output=True, text=True, timeout=120)
+            text = r.stdout + r.stderr
+            assert r.returncode >= 0 and "runtime error" not in text and "AddressSanitizer" not in text, (path, k, text[-2000:])
+            runs += 1
+    assert runs >= 100
+
+
 @pytest.mark.gpu
 def test_scene_program_renders_png(tmp_path):
     from PIL import Image
