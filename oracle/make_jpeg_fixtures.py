@@ -39,14 +39,22 @@ CASES = [  # name, width, height, mode, Pillow save options
     ("tiny", 1, 1, "RGB", dict(quality=90, subsampling=2)),
     ("narrow", 2, 37, "RGB", dict(quality=90, subsampling=2)),
     ("optimized", 33, 31, "RGB", dict(quality=88, subsampling=1, optimize=True)),
+    # progressive frames (SOF2): Pillow / libjpeg's default script = interleaved DC scan, spectral
+    # bands per component, successive-approximation refinements of DC and AC
+    ("progressive", 40, 30, "RGB", dict(quality=85, progressive=True)),
+    ("prog_444", 67, 45, "RGB", dict(quality=92, subsampling=0, progressive=True)),
+    ("prog_422", 35, 50, "RGB", dict(quality=80, subsampling=1, progressive=True)),
+    ("prog_420_q30", 83, 61, "RGB", dict(quality=30, subsampling=2, progressive=True)),
+    ("prog_gray", 41, 29, "L", dict(quality=80, progressive=True)),
+    ("prog_restart", 70, 40, "RGB", dict(quality=85, subsampling=2, progressive=True, restart_marker_blocks=2)),
+    ("prog_tiny", 3, 2, "RGB", dict(quality=90, subsampling=2, progressive=True)),
 ]
+SEEDS = {"progressive": 99}
 
 os.makedirs(OUT, exist_ok=True)
 for k, (name, w, h, mode, opts) in enumerate(CASES):
-    img = Image.fromarray(picture(w, h, k), "RGB").convert(mode)
+    img = Image.fromarray(picture(w, h, SEEDS.get(name, k)), "RGB").convert(mode)
     path = os.path.join(OUT, name + ".jpg")
     img.save(path, "JPEG", **opts)
     r = subprocess.run([REF, "image", path, os.path.join(OUT, name + ".rtimg")], capture_output=True, check=True)
     print(name, os.path.getsize(path), "bytes", r.stdout.decode().strip())
-# a progressive file: the reference's stb_image decodes it, this build's decoder refuses it
-Image.fromarray(picture(40, 30, 99), "RGB").save(os.path.join(OUT, "progressive.jpg"), "JPEG", quality=85, progressive=True)

@@ -1,4 +1,4 @@
-// rtamd_jpeg.hpp — baseline JPEG decoder for the drop-in's rtw_image (image_texture files such
+// rtamd_jpeg.hpp — JPEG decoder (sequential and progressive Huffman frames) for the drop-in's rtw_image (image_texture files such
 // as earthmap.jpg, rtw_stb_image.h:50-64).
 //
 // The reference decodes through stb_image (external/stb_image.h), and the texels feed the
@@ -10,8 +10,13 @@
 //   * chroma is upsampled with the 3:1 tent filters (stb_image.h:2848-2910) or replicated;
 //   * YCbCr -> RGB in 20-bit fixed point with 12-bit coefficients, the Cb term of green
 //     masked to 16 bits (stb_image.h:3071-3095).
-// Supported: 8-bit Huffman sequential frames (SOF0 / SOF1), 1 or 3 components, sampling
-// factors 1..4, restart intervals.  Progressive and arithmetic-coded files are rejected.
+//   * progressive frames keep their coefficients in 16-bit integers, refine them as
+//     stb_image.h:1748-1892 does and dequantise in 16 bits after the last scan
+//     (stb_image.h:2552-2575).
+// Supported: 8-bit Huffman frames, sequential (SOF0 / SOF1) or progressive (SOF2: spectral
+// selection and successive approximation), 1 or 3 components, sampling factors 1..4, any
+// number of scans (interleaved or one component each), restart intervals.  Lossless,
+// hierarchical and arithmetic-coded files are rejected.
 // Written from the JPEG specification (ITU T.81) and the numbers above; no code is shared
 // with stb_image.
 #pragma once
@@ -186,10 +191,110 @@ inline void idct8x8(const short coef[64], uint8_t *out, int out_stride) {
 
 struct Component {
     int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0;
+    int x = 0, y = 0;             // samples of this component that carry image data
     int plane_w = 0, plane_h = 0; // padded to whole MCUs
     int dc_pred = 0;
     std::vector<uint8_t> plane;
+    std::vector<short> coef; // progressive frames: 64 per block, zig-zag positions already undone
 };
+
+// One scan's parameters (T.81 B.2.3): spectral band [ss, se], successive-approximation bit
+// positions ah (0: first pass over the band) and al.
+struct Scan {
+    int n = 0, order[4] = {0, 0, 0, 0};
+    int ss = 0, se = 63, ah = 0, al = 0;
+};
+
+// Progressive DC (T.81 G.1.2.1): first pass = the sequential DC code, the value scaled by
+// 2^al; refinement = one more bit.  16-bit arithmetic as in stb_image.h:1756-1769.
+inline bool prog_dc(BitReader &br, const HuffTable &hd, Component &c, short *blk, const Scan &sc) {
+    if (sc.ah == 0) {
+        memset(blk, 0, 64 * sizeof(short));
+        int t = decode_symbol(br, hd);
+        if (t < 0 || t > 15) return false;
+        int diff = t ? extend(br.bits(t), t) : 0;
+        c.dc_pred += diff;
+        blk[0] = (short)(c.dc_pred * (1 << sc.al));
+    } else if (br.bit()) {
+        blk[0] = (short)(blk[0] + (short)(1 << sc.al));
+    }
+    return true;
+}
+
+// One more bit for a coefficient that is already non-zero (T.81 G.1.2.3; a coefficient whose
+// bit is already set is left alone, stb_image.h:1834 and 1874).
+inline void refine_nonzero(BitReader &br, short *p, short bit) {
+    if (br.bit() && (*p & bit) == 0) *p = (short)(*p > 0 ? *p + bit : *p - bit);
+}
+
+// Progressive AC (T.81 G.1.2.2, G.1.2.3) for one block; eob_run = blocks of this band still
+// covered by an end-of-band run.
+inline bool prog_ac(BitReader &br, const HuffTable &ha, short *blk, const Scan &sc, int &eob_run) {
+    if (sc.ah == 0) {
+        if (eob_run) {
+            eob_run--;
+            return true;
+        }
+        for (int k = sc.ss; k <= sc.se;) {
+            int rs = decode_symbol(br, ha);
+            if (rs < 0) return false;
+            int run = rs >> 4, sz = rs & 15;
+            if (sz == 0) {
+                if (run < 15) { // EOBn: this block and 2^run + bits - 1 more
+                    eob_run = (1 << run) - 1;
+                    if (run) eob_run += br.bits(run);
+                    break;
+                }
+                k += 16;
+                continue;
+            }
+            k += run;
+            if (k > 63) return false;
+            blk[kNatural[k]] = (short)(extend(br.bits(sz), sz) * (1 << sc.al));
+            k++;
+        }
+        return true;
+    }
+    const short bit = (short)(1 << sc.al);
+    if (eob_run) {
+        eob_run--;
+        for (int k = sc.ss; k <= sc.se; k++) {
+            short *p = &blk[kNatural[k]];
+            if (*p != 0) refine_nonzero(br, p, bit);
+        }
+        return true;
+    }
+    int k = sc.ss;
+    do {
+        int rs = decode_symbol(br, ha);
+        if (rs < 0) return false;
+        int run = rs >> 4, sz = rs & 15;
+        int value = 0;
+        if (sz == 0) {
+            if (run < 15) {
+                eob_run = (1 << run) - 1;
+                if (run) eob_run += br.bits(run);
+                run = 64; // the rest of the band: only the non-zero coefficients get their bit
+            }           // (run 15: sixteen zeros, the last of them "written" as 0)
+        } else {
+            if (sz != 1) return false;
+            value = br.bit() ? bit : -bit;
+        }
+        while (k <= sc.se) {
+            short *p = &blk[kNatural[k++]];
+            if (*p != 0) {
+                refine_nonzero(br, p, bit);
+            } else {
+                if (run == 0) {
+                    *p = (short)value;
+                    break;
+                }
+                run--;
+            }
+        }
+    } while (k <= sc.se);
+    return true;
+}
 
 // One output row of a component at full width (stb_image.h:3327-3360 row selection, filters
 // 2848-2910 and 3029-3037).
@@ -255,6 +360,110 @@ struct Upsampler {
 
 inline int be16(const uint8_t *p) { return (p[0] << 8) | p[1]; }
 
+// Entropy-coded data of one scan, from `pos`; returns the position at which marker parsing goes on.
+// Sequential frames: every block is dequantised and transformed as it is decoded.  Progressive
+// frames: the scan adds its band / bit to the stored coefficients (finish_progressive does the
+// rest once all scans are in).  A scan of one component covers that component's own
+// ceil(x / 8) x ceil(y / 8) blocks; a scan of several covers whole MCUs (T.81 A.2).
+inline bool decode_scan(const uint8_t *data, size_t size, size_t &pos, std::vector<Component> &comp, const Scan &sc,
+                        bool progressive, const HuffTable *dc_tab, const HuffTable *ac_tab, const uint8_t quant[4][64],
+                        int mcus_x, int mcus_y, int restart_interval, const char **why) {
+    BitReader br;
+    br.p = data + pos;
+    br.end = data + size;
+    int until_restart = restart_interval ? restart_interval : 0x7fffffff;
+    int eob_run = 0;
+    for (int k = 0; k < sc.n; k++) comp[(size_t)sc.order[k]].dc_pred = 0;
+    short block[64];
+    // one block of component c at block coordinates (bx, by)
+    auto do_block = [&](Component &c, int bx, int by) -> bool {
+        const HuffTable &hd = dc_tab[c.td], &ha = ac_tab[c.ta];
+        if (progressive) {
+            short *blk = c.coef.data() + 64 * ((size_t)by * (size_t)(c.plane_w / 8) + (size_t)bx);
+            if (sc.ss == 0) {
+                if (!prog_dc(br, hd, c, blk, sc)) return (*why = "bad DC code", false);
+            } else if (!prog_ac(br, ha, blk, sc, eob_run)) {
+                return (*why = "bad AC code", false);
+            }
+            return true;
+        }
+        const uint8_t *q = quant[c.tq];
+        memset(block, 0, sizeof(block));
+        int t = decode_symbol(br, hd);
+        if (t < 0 || t > 15) return (*why = "bad DC code", false);
+        int diff = t ? extend(br.bits(t), t) : 0;
+        c.dc_pred += diff;
+        block[0] = (short)(c.dc_pred * q[0]);
+        for (int k = 1; k < 64;) {
+            int rs = decode_symbol(br, ha);
+            if (rs < 0) return (*why = "bad AC code", false);
+            int run = rs >> 4, sz = rs & 15;
+            if (sz == 0) {
+                if (run != 15) break; // end of block
+                k += 16;
+                continue;
+            }
+            k += run;
+            if (k > 63) return (*why = "AC run past the end of the block", false);
+            int nat = kNatural[k];
+            block[nat] = (short)(extend(br.bits(sz), sz) * q[nat]);
+            k++;
+        }
+        idct8x8(block, c.plane.data() + (size_t)by * 8 * c.plane_w + (size_t)bx * 8, c.plane_w);
+        return true;
+    };
+    // RSTn after every restart_interval MCUs: byte-align, skip the marker, reset the predictors
+    auto mcu_done = [&](bool last) -> bool {
+        if (--until_restart != 0) return true;
+        until_restart = restart_interval;
+        if (last) return true;
+        const uint8_t *p = br.p;
+        while (p + 1 < br.end && !(p[0] == 0xff && p[1] >= 0xd0 && p[1] <= 0xd7)) p++;
+        if (p + 1 >= br.end) return (*why = "missing restart marker", false);
+        br.p = p + 2;
+        br.reset();
+        eob_run = 0;
+        for (int k = 0; k < sc.n; k++) comp[(size_t)sc.order[k]].dc_pred = 0;
+        return true;
+    };
+    if (sc.n == 1) {
+        Component &c = comp[(size_t)sc.order[0]];
+        const int bw = (c.x + 7) >> 3, bh = (c.y + 7) >> 3;
+        for (int by = 0; by < bh; by++)
+            for (int bx = 0; bx < bw; bx++) {
+                if (!do_block(c, bx, by)) return false;
+                if (!mcu_done(by == bh - 1 && bx == bw - 1)) return false;
+            }
+    } else {
+        for (int my = 0; my < mcus_y; my++)
+            for (int mx = 0; mx < mcus_x; mx++) {
+                for (int k = 0; k < sc.n; k++) {
+                    Component &c = comp[(size_t)sc.order[k]];
+                    for (int by = 0; by < c.v; by++)
+                        for (int bx = 0; bx < c.h; bx++)
+                            if (!do_block(c, mx * c.h + bx, my * c.v + by)) return false;
+                }
+                if (!mcu_done(my == mcus_y - 1 && mx == mcus_x - 1)) return false;
+            }
+    }
+    pos = (size_t)(br.p - data); // at or before the next marker (the reader never steps over one)
+    return true;
+}
+
+// Progressive frames, after the last scan: dequantise in 16 bits and transform the blocks that
+// carry image data (stb_image.h:2552-2575).
+inline void finish_progressive(std::vector<Component> &comp, const uint8_t quant[4][64]) {
+    for (Component &c : comp) {
+        const int bw = (c.x + 7) >> 3, bh = (c.y + 7) >> 3;
+        for (int by = 0; by < bh; by++)
+            for (int bx = 0; bx < bw; bx++) {
+                short *blk = c.coef.data() + 64 * ((size_t)by * (size_t)(c.plane_w / 8) + (size_t)bx);
+                for (int i = 0; i < 64; i++) blk[i] = (short)(blk[i] * quant[c.tq][i]);
+                idct8x8(blk, c.plane.data() + (size_t)by * 8 * c.plane_w + (size_t)bx * 8, c.plane_w);
+            }
+    }
+}
+
 } // namespace detail
 
 inline bool decode(const uint8_t *data, size_t size, Image &img, std::string *err = nullptr) {
@@ -268,16 +477,23 @@ inline bool decode(const uint8_t *data, size_t size, Image &img, std::string *er
     bool quant_ok[4] = {false, false, false, false};
     HuffTable dc_tab[4], ac_tab[4];
     std::vector<Component> comp;
-    int width = 0, height = 0, restart_interval = 0, h_max = 1, v_max = 1;
+    int width = 0, height = 0, restart_interval = 0, h_max = 1, v_max = 1, mcus_x = 0, mcus_y = 0;
     size_t pos = 2;
-    bool have_frame = false, done = false;
-    while (!done) {
+    bool have_frame = false, progressive = false;
+    int n_scans = 0;
+    for (;;) {
         while (pos < size && data[pos] != 0xff) pos++; // tolerate garbage between segments
         while (pos < size && data[pos] == 0xff) pos++; // fill bytes
-        if (pos >= size) return fail("truncated file (no scan)");
+        if (pos >= size) {
+            if (n_scans > 0) break; // no EOI marker: what has been decoded stands
+            return fail("truncated file (no scan)");
+        }
         const int marker = data[pos++];
-        if (marker == 0xd9) return fail("end of image before any scan");
-        if (marker == 0x01 || (marker >= 0xd0 && marker <= 0xd7)) continue; // no payload
+        if (marker == 0xd9) {
+            if (n_scans > 0) break;
+            return fail("end of image before any scan");
+        }
+        if (marker == 0x00 || marker == 0x01 || (marker >= 0xd0 && marker <= 0xd7)) continue; // no payload
         if (pos + 2 > size) return fail("truncated segment");
         const int len = be16(data + pos);
         if (len < 2 || pos + (size_t)len > size) return fail("bad segment length");
@@ -312,7 +528,8 @@ inline bool decode(const uint8_t *data, size_t size, Image &img, std::string *er
             break;
         }
         case 0xc0:
-        case 0xc1: { // SOF0 / SOF1: Huffman, sequential
+        case 0xc1:
+        case 0xc2: { // SOF0 / SOF1: Huffman, sequential; SOF2: Huffman, progressive
             if (have_frame) return fail("more than one frame");
             if (n < 6) return fail("bad SOF");
             if (seg[0] != 8) return fail("only 8-bit samples are supported");
@@ -332,13 +549,25 @@ inline bool decode(const uint8_t *data, size_t size, Image &img, std::string *er
                 if (comp[i].h > h_max) h_max = comp[i].h;
                 if (comp[i].v > v_max) v_max = comp[i].v;
             }
+            progressive = marker == 0xc2;
+            if (nc == 1) comp[0].h = comp[0].v = h_max = v_max = 1; // a lone component is not interleaved
+            mcus_x = (width + 8 * h_max - 1) / (8 * h_max);
+            mcus_y = (height + 8 * v_max - 1) / (8 * v_max);
+            for (Component &c : comp) {
+                c.x = (width * c.h + h_max - 1) / h_max;
+                c.y = (height * c.v + v_max - 1) / v_max;
+                c.plane_w = mcus_x * c.h * 8;
+                c.plane_h = mcus_y * c.v * 8;
+                c.plane.assign((size_t)c.plane_w * c.plane_h, 0);
+                if (progressive) c.coef.assign((size_t)c.plane_w * c.plane_h, 0);
+            }
             have_frame = true;
             break;
         }
-        case 0xc2: case 0xc3: case 0xc5: case 0xc6: case 0xc7: case 0xc9: case 0xca: case 0xcb: case 0xcd:
+        case 0xc3: case 0xc5: case 0xc6: case 0xc7: case 0xc9: case 0xca: case 0xcb: case 0xcd:
         case 0xce: case 0xcf:
-            return fail("only baseline / sequential Huffman JPEG is supported (this file is progressive, "
-                        "lossless or arithmetic-coded)");
+            return fail("only Huffman-coded sequential and progressive JPEG is supported (this file is lossless, "
+                        "hierarchical or arithmetic-coded)");
         case 0xdd: // DRI
             if (n < 2) return fail("bad DRI");
             restart_interval = be16(seg);
@@ -346,19 +575,49 @@ inline bool decode(const uint8_t *data, size_t size, Image &img, std::string *er
         case 0xda: { // SOS
             if (!have_frame) return fail("scan before frame");
             if (n < 1) return fail("bad SOS");
-            int ns = seg[0];
-            if (ns != (int)comp.size() || n < 1 + 2 * ns + 3) return fail("only one interleaved scan is supported");
-            for (int i = 0; i < ns; i++) {
-                int cid = seg[1 + 2 * i], tt = seg[2 + 2 * i];
-                if (cid != comp[i].id) return fail("scan component order differs from the frame");
-                comp[i].td = tt >> 4;
-                comp[i].ta = tt & 15;
-                if (comp[i].td > 3 || comp[i].ta > 3 || !dc_tab[comp[i].td].present || !ac_tab[comp[i].ta].present)
+            Scan sc;
+            sc.n = seg[0];
+            if (sc.n < 1 || sc.n > (int)comp.size() || n != 1 + 2 * sc.n + 3) return fail("bad SOS");
+            for (int i = 0; i < sc.n; i++) {
+                int cid = seg[1 + 2 * i], tt = seg[2 + 2 * i], which = -1;
+                for (size_t k = 0; k < comp.size(); k++)
+                    if (comp[k].id == cid) {
+                        which = (int)k;
+                        break;
+                    }
+                if (which < 0) return fail("scan names a component the frame does not have");
+                for (int k = 0; k < i; k++)
+                    if (sc.order[k] == which) return fail("scan names a component twice");
+                sc.order[i] = which;
+                comp[(size_t)which].td = tt >> 4;
+                comp[(size_t)which].ta = tt & 15;
+                if (comp[(size_t)which].td > 3 || comp[(size_t)which].ta > 3) return fail("bad Huffman table index");
+                if (!quant_ok[comp[(size_t)which].tq]) return fail("component refers to a missing quantisation table");
+            }
+            sc.ss = seg[1 + 2 * sc.n];
+            sc.se = seg[2 + 2 * sc.n];
+            sc.ah = seg[3 + 2 * sc.n] >> 4;
+            sc.al = seg[3 + 2 * sc.n] & 15;
+            if (progressive) {
+                if (sc.ss > 63 || sc.se > 63 || sc.ss > sc.se || sc.ah > 13 || sc.al > 13) return fail("bad SOS");
+                if (sc.ss == 0 && sc.se != 0) return fail("a progressive scan mixes DC and AC coefficients");
+                if (sc.ss != 0 && sc.n != 1) return fail("a progressive AC scan covers one component");
+            } else {
+                if (sc.ss != 0 || sc.ah != 0 || sc.al != 0) return fail("bad SOS");
+                sc.se = 63;
+            }
+            for (int i = 0; i < sc.n; i++) { // the tables this scan decodes with
+                const Component &c = comp[(size_t)sc.order[i]];
+                const bool need_dc = !progressive || (sc.ss == 0 && sc.ah == 0), need_ac = !progressive || sc.ss != 0;
+                if ((need_dc && !dc_tab[c.td].present) || (need_ac && !ac_tab[c.ta].present))
                     return fail("scan refers to a missing Huffman table");
-                if (!quant_ok[comp[i].tq]) return fail("component refers to a missing quantisation table");
             }
             pos += (size_t)len;
-            done = true;
+            const char *why = "corrupt scan";
+            if (!decode_scan(data, size, pos, comp, sc, progressive, dc_tab, ac_tab, quant, mcus_x, mcus_y,
+                             restart_interval, &why))
+                return fail(why);
+            n_scans++;
             continue;
         }
         default: // APPn, COM and anything else with a length
@@ -366,69 +625,7 @@ inline bool decode(const uint8_t *data, size_t size, Image &img, std::string *er
         }
         pos += (size_t)len;
     }
-
-    // ---- entropy-coded data: one interleaved scan ------------------------------------------------
-    if (comp.size() == 1) comp[0].h = comp[0].v = h_max = v_max = 1; // a lone component is not interleaved
-    const int mcu_w = 8 * h_max, mcu_h = 8 * v_max;
-    const int mcus_x = (width + mcu_w - 1) / mcu_w, mcus_y = (height + mcu_h - 1) / mcu_h;
-    for (Component &c : comp) {
-        c.plane_w = mcus_x * c.h * 8;
-        c.plane_h = mcus_y * c.v * 8;
-        c.plane.assign((size_t)c.plane_w * c.plane_h, 0);
-        c.dc_pred = 0;
-    }
-    BitReader br;
-    br.p = data + pos;
-    br.end = data + size;
-    int until_restart = restart_interval ? restart_interval : 0x7fffffff;
-    short block[64];
-    for (int my = 0; my < mcus_y; my++) {
-        for (int mx = 0; mx < mcus_x; mx++) {
-            for (Component &c : comp) {
-                const HuffTable &hd = dc_tab[c.td], &ha = ac_tab[c.ta];
-                const uint8_t *q = quant[c.tq];
-                for (int by = 0; by < c.v; by++) {
-                    for (int bx = 0; bx < c.h; bx++) {
-                        memset(block, 0, sizeof(block));
-                        int t = decode_symbol(br, hd);
-                        if (t < 0 || t > 15) return fail("bad DC code");
-                        int diff = t ? extend(br.bits(t), t) : 0;
-                        c.dc_pred += diff;
-                        block[0] = (short)(c.dc_pred * q[0]);
-                        for (int k = 1; k < 64;) {
-                            int rs = decode_symbol(br, ha);
-                            if (rs < 0) return fail("bad AC code");
-                            int run = rs >> 4, sz = rs & 15;
-                            if (sz == 0) {
-                                if (run != 15) break; // end of block
-                                k += 16;
-                                continue;
-                            }
-                            k += run;
-                            if (k > 63) return fail("AC run past the end of the block");
-                            int nat = kNatural[k];
-                            block[nat] = (short)(extend(br.bits(sz), sz) * q[nat]);
-                            k++;
-                        }
-                        uint8_t *dst = c.plane.data() + (size_t)(my * c.v + by) * 8 * c.plane_w + (size_t)(mx * c.h + bx) * 8;
-                        idct8x8(block, dst, c.plane_w);
-                    }
-                }
-            }
-            if (--until_restart == 0) { // RSTn: byte-align, skip the marker, reset the predictors
-                until_restart = restart_interval;
-                const bool last = my == mcus_y - 1 && mx == mcus_x - 1;
-                if (!last) {
-                    const uint8_t *p = br.p;
-                    while (p + 1 < br.end && !(p[0] == 0xff && p[1] >= 0xd0 && p[1] <= 0xd7)) p++;
-                    if (p + 1 >= br.end) return fail("missing restart marker");
-                    br.p = p + 2;
-                    br.reset();
-                    for (Component &c : comp) c.dc_pred = 0;
-                }
-            }
-        }
-    }
+    if (progressive) finish_progressive(comp, quant);
 
     // ---- upsample and convert ----------------------------------------------------------------------
     img.width = width;

@@ -60,14 +60,15 @@ def test_raw_texel_dump_is_accepted_too(tmp_path):
 
 
 JPEG_DIR = os.path.join(GOLDEN, "jpeg")
-JPEG_CASES = sorted(f[:-4] for f in os.listdir(JPEG_DIR) if f.endswith(".jpg") and f != "progressive.jpg")
+JPEG_CASES = sorted(f[:-4] for f in os.listdir(JPEG_DIR) if f.endswith(".jpg"))
 
 
 @pytest.mark.parametrize("name", JPEG_CASES)
 def test_jpeg_decoder_matches_the_reference_texels(name, tmp_path):
     """tests/golden/jpeg/<name>.rtimg holds what the unmodified reference (rtw_image over
     stb_image) makes of <name>.jpg (oracle/make_jpeg_fixtures.py): sampling 4:4:4 / 4:2:2 /
-    4:2:0, grayscale, restart intervals, odd sizes.  The drop-in's decoder must give the same
+    4:2:0, grayscale, restart intervals, odd sizes, and progressive frames (spectral bands,
+    successive approximation, restart intervals).  The drop-in's decoder must give the same
     bytes.  (Vertical-only subsampling is not covered: Pillow cannot write it.)"""
     _ensure_built()
     out = str(tmp_path / "out.rtimg")
@@ -76,11 +77,31 @@ def test_jpeg_decoder_matches_the_reference_texels(name, tmp_path):
     assert open(out, "rb").read() == open(os.path.join(JPEG_DIR, name + ".rtimg"), "rb").read()
 
 
-def test_progressive_jpeg_is_refused_loudly(tmp_path):
+def test_arithmetic_coded_jpeg_is_refused_loudly(tmp_path):
+    """A frame type the decoder does not implement (here SOF9, arithmetic coding: the frame marker of
+    a sequential file rewritten) is an error with a message, not a wrong picture."""
     _ensure_built()
-    r = subprocess.run([os.path.join(BIN, "rt_image"), os.path.join(JPEG_DIR, "progressive.jpg"),
-                        str(tmp_path / "o.rtimg")], capture_output=True)
-    assert r.returncode != 0 and b"progressive" in r.stderr
+    raw = bytearray(open(os.path.join(JPEG_DIR, "s444.jpg"), "rb").read())
+    k = raw.find(b"\xff\xc0")
+    assert k > 0
+    raw[k + 1] = 0xC9
+    src = tmp_path / "arith.jpg"
+    src.write_bytes(bytes(raw))
+    r = subprocess.run([os.path.join(BIN, "rt_image"), str(src), str(tmp_path / "o.rtimg")], capture_output=True)
+    assert r.returncode != 0 and b"arithmetic" in r.stderr
+
+
+def test_truncated_progressive_jpeg_does_not_crash(tmp_path):
+    """Cut anywhere, a progressive file either decodes to a picture of the right size or fails with a
+    message (never a crash or a hang)."""
+    _ensure_built()
+    raw = open(os.path.join(JPEG_DIR, "prog_420_q30.jpg"), "rb").read()
+    for cut in range(len(raw) // 7, len(raw), max(1, len(raw) // 23)):
+        src = tmp_path / f"cut{cut}.jpg"
+        src.write_bytes(raw[:cut])
+        r = subprocess.run([os.path.join(BIN, "rt_image"), str(src), str(tmp_path / "o.rtimg")], capture_output=True,
+                           timeout=20)
+        assert r.returncode in (0, 1), (cut, r.returncode, r.stderr[-200:])
 
 
 def test_missing_image_is_not_fatal(tmp_path):
