@@ -207,6 +207,32 @@ static void cornell_box() {
     shoot(world, View{1.0f, 600, 10, kBlack, 40.0f, point3(278.0f, 278.0f, -800.0f), point3(278.0f, 278.0f, 0.0f), 0.0f, 10.0f});
 }
 
+// Rotated objects inside a bvh_node (not one of main.cpp's scenes): the reference's rotate_y /
+// rotate_xyz constructors leave a box that is too small (hittable.h:123-126, 241-244) and its
+// bvh_node::hit culls with it (bvh.h:78).  The drop-in's host-side hit() reproduces that; the GPU
+// renderer bounds the flattened primitives itself and shows the whole objects.
+static void rotated_in_bvh() {
+    hittable_list world;
+    world.add(make_shared<sphere>(point3(0.0f, -1000.0f, 0.0f), 1000.0f, make_shared<lambertian>(color(0.5f, 0.5f, 0.5f))));
+    for (int a = -3; a <= 3; a++)
+        for (int b = -3; b <= 3; b++) {
+            if (a * a + b * b < 3) continue;
+            point3 c(1.6f * a + 0.2f * (b & 1), 0.3f, 1.6f * b);
+            shared_ptr<material> mat;
+            if ((a + b) & 1) mat = make_shared<metal>(color(0.8f, 0.7f, 0.6f), 0.1f);
+            else mat = make_shared<lambertian>(color(0.2f + 0.1f * (a + 3), 0.3f, 0.8f - 0.1f * (b + 3)));
+            world.add(make_shared<sphere>(c, 0.3f, mat));
+        }
+    shared_ptr<hittable> slab = box(point3(-1.5f, 0.0f, -0.4f), point3(1.5f, 1.2f, 0.4f), make_shared<lambertian>(color(0.73f, 0.73f, 0.73f)));
+    world.add(make_shared<rotate_y>(slab, 40.0f));
+    shared_ptr<hittable> ball = make_shared<sphere>(point3(0.9f, 0.0f, 0.0f), 0.6f, make_shared<metal>(color(0.9f, 0.9f, 0.9f), 0.0f));
+    world.add(make_shared<translate>(make_shared<rotate_xyz>(ball, 25.0f, 50.0f, 10.0f), vec3(-3.0f, 1.4f, 1.0f)));
+    shared_ptr<hittable> post = box(point3(0.0f, 0.0f, 0.0f), point3(0.5f, 2.0f, 0.5f), make_shared<lambertian>(color(0.65f, 0.05f, 0.05f)));
+    world.add(make_shared<translate>(make_shared<rotate_y>(post, -30.0f), vec3(2.5f, 0.0f, -1.5f)));
+    world = hittable_list(make_shared<bvh_node>(world));
+    shoot(world, View{kWide, 240, 10, kSky, 35.0f, point3(6.0f, 4.0f, 9.0f), point3(0.0f, 0.8f, 0.0f), 0.0f, 10.0f});
+}
+
 // 10^6 cells on a grid, one sphere or quad per cell, plus the ground: splitmix64 keyed layout,
 // twelve draws per cell whether they are used or not.
 static void synth1m(int half) {
@@ -267,6 +293,7 @@ int main(int argc, char **argv) {
     else if (s == "quads") quads();
     else if (s == "simple_light") simple_light();
     else if (s == "cornell_box") cornell_box();
+    else if (s == "rotated_in_bvh") rotated_in_bvh();
     else if (s == "synth1m") synth1m(synth_half);
     else {
         fprintf(stderr, "unknown scene %s\n", argv[1]);

@@ -29,6 +29,8 @@ SCENES = ["bouncing_spheres", "checkered_spheres", "earth", "perlin_spheres", "q
 # spp of the converged reference images (the PSNR >= 40 dB gate needs about this much)
 IMAGE_SPP = {"bouncing_spheres": 1024, "checkered_spheres": 1024, "earth": 1024,
              "perlin_spheres": 1024, "quads": 1024, "simple_light": 8192, "cornell_box": 16384}
+# scenes of the harness itself (not in main.cpp): scene dump, camera and ray records only
+EXTRA_SCENES = ["rotated_in_bvh"]
 RAY_PATHS = 1500
 PIN_SPP = 2
 PIN_ROWS = 24
@@ -42,12 +44,12 @@ def run(args):
 
 
 def stage_scenes():
-    for s in SCENES:
+    for s in SCENES + EXTRA_SCENES:
         print(run(["dump", s, f"{GOLD}/{s}.rtscene", f"{GOLD}/{s}.cam"]))
 
 
 def stage_rays():
-    for s in SCENES:
+    for s in SCENES + EXTRA_SCENES:
         print(run(["rays", s, RAY_PATHS, f"{GOLD}/{s}.rays"]))
 
 

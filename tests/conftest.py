@@ -10,6 +10,10 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 SCENES = ["bouncing_spheres", "checkered_spheres", "earth", "perlin_spheres", "quads",
           "simple_light", "cornell_box"]
+# Scenes of the reference harness itself (not in the reference's main.cpp), with a scene dump, a camera
+# and ray records only.  rotated_in_bvh: rotated objects inside a bvh_node, which the reference clips
+# to the too-small boxes of its rotate_y / rotate_xyz constructors (hittable.h:123-126, 241-244).
+EXTRA_SCENES = ["rotated_in_bvh"]
 
 
 def pytest_configure(config):

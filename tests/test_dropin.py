@@ -15,7 +15,7 @@ import pytest
 
 from raytracing_amd import abi
 from tests import oracle_lib as O
-from tests.conftest import GOLDEN, ROOT, SCENES, load_scene
+from tests.conftest import EXTRA_SCENES, GOLDEN, ROOT, SCENES, load_scene
 
 BIN = os.path.join(ROOT, "examples", "bin")
 RT_SCENES = os.path.join(BIN, "rt_scenes")
@@ -35,7 +35,7 @@ def _write_rtimg(path, arrays):
         f.write(arrays.texels[int(im["offset"]):int(im["offset"]) + n].tobytes())
 
 
-@pytest.mark.parametrize("scene", SCENES)
+@pytest.mark.parametrize("scene", SCENES + EXTRA_SCENES)
 def test_scene_programs_flatten_like_the_reference(scene, tmp_path):
     _ensure_built()
     env = dict(os.environ)
@@ -138,12 +138,14 @@ def test_synth1m_scene_shape(tmp_path):
     assert (frame.image_width, frame.image_height) == (3840, 2160)
 
 
-@pytest.mark.parametrize("scene", SCENES)
+@pytest.mark.parametrize("scene", SCENES + EXTRA_SCENES)
 def test_host_side_hit_matches_the_reference_records(scene, tmp_path):
     """hittable::hit on the drop-in classes (sphere, quad, hittable_list, bvh_node, the instance
     wrappers; hittable.h:34-36), called on the host for the rays the reference recorded: hit /
     miss, t, p, normal and face bit for bit, u / v bit for bit as well (glibc's acosf / atan2f on
-    both sides).  The primitive id has no counterpart in hit_record."""
+    both sides).  The primitive id has no counterpart in hit_record.  rotated_in_bvh: the
+    reference clips rotated objects inside a bvh_node to their too-small boxes, and so must
+    bvh_node::hit of the drop-in."""
     rays_file = os.path.join(GOLDEN, scene + ".rays")
     out = str(tmp_path / "hits.bin")
     env = dict(os.environ, RTW_IMAGES=os.path.join(GOLDEN, "images"))
