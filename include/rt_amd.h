@@ -257,8 +257,9 @@ int rt_scene_create(const rt_scene_desc *desc, int device, uint32_t flags, rt_sc
 int rt_scene_destroy(rt_scene *scene);
 int rt_scene_get_info(const rt_scene *scene, rt_scene_info *out);
 /* Diagnostic (no counterpart in the reference): copies the nodes of the scene's 4-wide BVH back
- * to the host, n_nodes x 128 bytes = 32 words: words 6k .. 6k+5 = centre (3) and half extent (3)
- * of child k's box, words 24..27 = the four child references (int; >= 0 inner node, < 0 leaf
+ * to the host, n_nodes x 128 bytes = 32 words: words 8a + k and 8a + 4 + k = the lower and the
+ * upper plane of child k's box along axis a (a = 0, 1, 2: the planes of the four children are
+ * grouped by axis), words 24..27 = the four child references (int; >= 0 inner node, < 0 leaf
  * ~(slot*2 + type)), word 28 = number of children (int, 2..4; an unused child has an inverted
  * box, which no finite ray enters, and the reference of some real leaf), words 29..31 unused. */
 int rt_scene_read_nodes(rt_scene *scene, void *out, uint64_t bytes);

@@ -568,6 +568,9 @@ struct BoxRay { // per-ray constants of the slab test
     f3 inv;  // ~1/d (a zero component is replaced by a huge finite reciprocal)
     f3 oi;   // -(o * inv)
     float e2; // absolute slack: covers the rounding of o*inv inside fma(plane, inv, -o*inv)
+    // byte offset of the ray's NEAR plane inside an axis' {lo[4]} {hi[4]} pair of a node: 0 where the
+    // direction component is positive (lo is entered first), 16 where it is negative
+    int sx, sy, sz;
 };
 RT_HD float safe_rcp(float d) {
     // |d| below 1e-30 would overflow; a slab that the ray runs (almost) parallel to
@@ -594,7 +597,23 @@ RT_HD BoxRay make_box_ray(const Ray &r) {
     float my = fabsf(r.d.y) < 1e-30f ? 0.0f : fabsf(oi.y);
     float mz = fabsf(r.d.z) < 1e-30f ? 0.0f : fabsf(oi.z);
     b.e2 = 9.5367431640625e-7f * fmaxf(mx, fmaxf(my, mz));
+    // (the sign of the reciprocal is the sign of the direction component, zeros included)
+    b.sx = (int)((__builtin_bit_cast(unsigned, b.inv.x) >> 31) << 4);
+    b.sy = (int)((__builtin_bit_cast(unsigned, b.inv.y) >> 31) << 4);
+    b.sz = (int)((__builtin_bit_cast(unsigned, b.inv.z) >> 31) << 4);
     return b;
+}
+// The same test from the ray's near and far planes of each axis (a node stores them apart, so that
+// a ray loads the ones it enters and leaves through directly): two FMAs per axis.
+RT_HD bool box_hit_planes(float px, float py, float pz, float qx, float qy, float qz, const BoxRay &b, float tmin,
+                          float tmax, float &tn) {
+    float nx = __builtin_fmaf(px, b.inv.x, b.oi.x), fx = __builtin_fmaf(qx, b.inv.x, b.oi.x);
+    float ny = __builtin_fmaf(py, b.inv.y, b.oi.y), fy = __builtin_fmaf(qy, b.inv.y, b.oi.y);
+    float nz = __builtin_fmaf(pz, b.inv.z, b.oi.z), fz = __builtin_fmaf(qz, b.inv.z, b.oi.z);
+    tn = fmaxf(fmaxf(fmaxf(nx, ny), nz), tmin);
+    float tf = fminf(fminf(fminf(fx, fy), fz), tmax);
+    float tf_wide = __builtin_fmaf(tf, 1.0f + 1.9073486328125e-6f, b.e2); // (see box_hit)
+    return tn <= tf_wide;
 }
 // Conservative ray/box overlap on [tmin, tmax] for a box given as centre c and half extent
 // h: true if the box may be hit, tn = the (slightly early) entry parameter.  With
@@ -737,34 +756,72 @@ RT_HD void sort4_desc(unsigned k0, unsigned k1, unsigned k2, unsigned k3, unsign
 
 // One inner node (requires tv.ref >= 0) of the 4-wide tree: tests the four child boxes, puts
 // the children that are hit on the stack, farthest first, and takes the nearest back.
-// Node, 8 x 16 bytes: the boxes as centre c and half extent h
-//   {c0.xyz h0.x} {h0.yz c1.xy} {c1.z h1.xyz} {c2.xyz h2.x} {h2.yz c3.xy} {c3.z h3.xyz}
+// Node, 8 x 16 bytes: the planes of the four child boxes grouped by axis
+//   {lo_x[0..3]} {hi_x[0..3]} {lo_y[0..3]} {hi_y[0..3]} {lo_z[0..3]} {hi_z[0..3]}
 //   {ref0 ref1 ref2 ref3} {number of children, - - -}
-// An unused child has an inverted box (never hit).  The four keys (0 for a child that is
-// missed) are sorted in descending order with integer min / max and all four are written
-// above the stack's top: the farthest child lands lowest, the missed ones above the new top
-// where they do not count.  No branch depends on how many children were hit.
+// A ray reads, per axis, the plane it enters through and the one it leaves through (lo then hi for
+// a positive direction component, hi then lo for a negative one: BoxRay::sx/sy/sz), so that a box
+// costs two FMAs per axis and no per-axis min / max.  An unused child has an inverted box (never
+// hit).  The four keys (0 for a child that is missed) are sorted in descending order with integer
+// min / max and all four are written above the stack's top: the farthest child lands lowest, the
+// missed ones above the new top where they do not count.  No branch depends on how many children
+// were hit.
 // TOP: nodes [0, n_top) are read from `top` (the workgroup's LDS) instead of `nodes` (HBM).
 // NODE_F4: spacing of `nodes` (RT_NODE_F4 in global memory, RT_NODE_LDS_F4 for a copy in LDS).
+// The loads name their address space (LDS or global memory) themselves: the scene kept in HBM
+// with the top of its tree in LDS has both kinds of node in one kernel, and with plain pointers the
+// compiler merges the two paths into flat loads through a selected pointer.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RT_AS_LDS __attribute__((address_space(3)))
+#define RT_AS_GLOBAL __attribute__((address_space(1)))
+#else
+#define RT_AS_LDS
+#define RT_AS_GLOBAL
+#endif
+struct NodePlanes {
+    f4 px, qx, py, qy, pz, qz, refs; // near (p) and far (q) planes per axis, child references
+    int n_children;
+};
+template <bool COUNT> RT_HD NodePlanes node_planes_lds(const f4 *node, const BoxRay &b) {
+    const RT_AS_LDS char *n = (const RT_AS_LDS char *)node;
+    NodePlanes r;
+    r.px = *(const RT_AS_LDS f4 *)(n + b.sx), r.qx = *(const RT_AS_LDS f4 *)(n + (16 - b.sx));
+    r.py = *(const RT_AS_LDS f4 *)(n + 32 + b.sy), r.qy = *(const RT_AS_LDS f4 *)(n + 32 + (16 - b.sy));
+    r.pz = *(const RT_AS_LDS f4 *)(n + 64 + b.sz), r.qz = *(const RT_AS_LDS f4 *)(n + 64 + (16 - b.sz));
+    r.refs = *(const RT_AS_LDS f4 *)(n + 96);
+    r.n_children = COUNT ? *(const RT_AS_LDS int *)(n + 112) : 0;
+    return r;
+}
+template <bool COUNT> RT_HD NodePlanes node_planes_global(const f4 *node, const BoxRay &b) {
+    const RT_AS_GLOBAL char *n = (const RT_AS_GLOBAL char *)node;
+    NodePlanes r;
+    r.px = *(const RT_AS_GLOBAL f4 *)(n + b.sx), r.qx = *(const RT_AS_GLOBAL f4 *)(n + (16 - b.sx));
+    r.py = *(const RT_AS_GLOBAL f4 *)(n + 32 + b.sy), r.qy = *(const RT_AS_GLOBAL f4 *)(n + 32 + (16 - b.sy));
+    r.pz = *(const RT_AS_GLOBAL f4 *)(n + 64 + b.sz), r.qz = *(const RT_AS_GLOBAL f4 *)(n + 64 + (16 - b.sz));
+    r.refs = *(const RT_AS_GLOBAL f4 *)(n + 96);
+    r.n_children = COUNT ? *(const RT_AS_GLOBAL int *)(n + 112) : 0;
+    return r;
+}
+// NODES_IN_LDS: `nodes` itself is a copy in LDS (the whole scene is); else it is global memory.
 template <bool COUNT, class ST, bool TOP, bool SPILL, int NODE_F4 = RT_NODE_F4>
 RT_HD void trav_inner(Trav &tv, const f4 *nodes, float tmin, const ST &st, int ref_bits, Cnt<COUNT> &cn,
                       const f4 *top = nullptr, int n_top = 0) {
     typedef typename ST::elem T;
-    f4 q0, q1, q2, q3, q4, q5, q6;
+    NodePlanes np;
     if (TOP && tv.ref < n_top) { // two explicit paths: LDS reads and global loads, no flat addressing
-        const f4 *n = top + lds_node_words(tv.ref);
-        q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3], q4 = n[4], q5 = n[5], q6 = n[6];
-        if constexpr (COUNT) cn.box += __builtin_bit_cast(int, n[7].x);
+        np = node_planes_lds<COUNT>(top + lds_node_words(tv.ref), tv.br);
+    } else if (NODE_F4 == RT_NODE_LDS_F4) {
+        np = node_planes_lds<COUNT>(nodes + lds_node_words(tv.ref), tv.br);
     } else {
-        const f4 *n = nodes + (NODE_F4 == RT_NODE_LDS_F4 ? (size_t)lds_node_words(tv.ref) : (size_t)tv.ref * NODE_F4);
-        q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3], q4 = n[4], q5 = n[5], q6 = n[6];
-        if constexpr (COUNT) cn.box += __builtin_bit_cast(int, n[7].x);
+        np = node_planes_global<COUNT>(nodes + (size_t)tv.ref * NODE_F4, tv.br);
     }
+    if constexpr (COUNT) cn.box += np.n_children;
+    const f4 px = np.px, qx = np.qx, py = np.py, qy = np.qy, pz = np.pz, qz = np.qz, q6 = np.refs;
     float e0, e1, e2, e3;
-    const bool h0 = box_hit(mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), tv.br, tmin, tv.best_t, e0);
-    const bool h1 = box_hit(mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w), tv.br, tmin, tv.best_t, e1);
-    const bool h2 = box_hit(mk(q3.x, q3.y, q3.z), mk(q3.w, q4.x, q4.y), tv.br, tmin, tv.best_t, e2);
-    const bool h3 = box_hit(mk(q4.z, q4.w, q5.x), mk(q5.y, q5.z, q5.w), tv.br, tmin, tv.best_t, e3);
+    const bool h0 = box_hit_planes(px.x, py.x, pz.x, qx.x, qy.x, qz.x, tv.br, tmin, tv.best_t, e0);
+    const bool h1 = box_hit_planes(px.y, py.y, pz.y, qx.y, qy.y, qz.y, tv.br, tmin, tv.best_t, e1);
+    const bool h2 = box_hit_planes(px.z, py.z, pz.z, qx.z, qy.z, qz.z, tv.br, tmin, tv.best_t, e2);
+    const bool h3 = box_hit_planes(px.w, py.w, pz.w, qx.w, qy.w, qz.w, tv.br, tmin, tv.best_t, e3);
     const unsigned hi = ref_bits >= 32 ? 0u : ~((1u << ref_bits) - 1u); // the bits of a key that hold the distance
     // (the keys first, then the selects: a key built inside the conditional would become a branch)
     const unsigned u0 = key_of(hi, e0, q6.x), u1 = key_of(hi, e1, q6.y), u2 = key_of(hi, e2, q6.z), u3 = key_of(hi, e3, q6.w);

@@ -399,6 +399,36 @@ inline int reorder_tree_top(std::vector<f4> &nodes, int max_top) {
     return (int)picked.size();
 }
 
+// The node layout the kernels read (rt_core.h trav_inner): the builders and the passes above work
+// on child boxes as centre + half extent, six floats per child; this last pass turns every node
+// into planes grouped by axis, {lo_x of the four children} {hi_x} {lo_y} {hi_y} {lo_z} {hi_z},
+// so that a ray reads its near and its far plane of an axis with one 16-byte load each, picked by
+// the sign of its direction.  lo = c - h and hi = c + h are rounded outwards (the stored box
+// contains the built one); an unused child keeps an inverted box.
+inline void nodes_to_plane_layout(std::vector<f4> &nodes) {
+    const size_t n = nodes.size() / 8;
+    for (size_t i = 0; i < n; i++) {
+        float *q = reinterpret_cast<float *>(&nodes[i * 8]);
+        float lo[3][4], hi[3][4];
+        for (int k = 0; k < 4; k++)
+            for (int a = 0; a < 3; a++) {
+                const float c = q[6 * k + a], h = q[6 * k + 3 + a];
+                if (h < 0.0f) { // unused child
+                    lo[a][k] = 1e30f;
+                    hi[a][k] = -1e30f;
+                } else {
+                    lo[a][k] = std::nextafter(c - h, -INFINITY);
+                    hi[a][k] = std::nextafter(c + h, INFINITY);
+                }
+            }
+        for (int a = 0; a < 3; a++)
+            for (int k = 0; k < 4; k++) {
+                q[8 * a + k] = lo[a][k];
+                q[8 * a + 4 + k] = hi[a][k];
+            }
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // Binned-SAH builder of the binary tree.  Leaves hold one primitive; a parent stores the
 // boxes of both children.
@@ -771,6 +801,7 @@ inline int flatten_scene(const rt_scene_desc *d, uint32_t flags, HostScene &out,
         nodes = std::move(wide.nodes);
         // trees too large for LDS: their top is cached there (kTreeTopMin nodes is more than a CU's LDS holds)
         out.n_top = wide.n_nodes >= kTreeTopMin ? reorder_tree_top(nodes, kTreeTopMax) : 0;
+        nodes_to_plane_layout(nodes);
         slots.resize((size_t)n * slot_f4);
         for (int sl = 0; sl < n; sl++) {
             int pi = bo.leaf_order[sl];

@@ -265,12 +265,11 @@ def _tree_stats(nodes):
         nd = nodes[i]
         assert 2 <= refs[i, 4] <= 4
         for k in range(4):
-            centre, half = nd[6 * k:6 * k + 3], nd[6 * k + 3:6 * k + 6]
+            lo, hi = nd[k:24:8], nd[4 + k:24:8]  # {lo_x[4]} {hi_x[4]} {lo_y[4]} {hi_y[4]} {lo_z[4]} {hi_z[4]}
             if k >= refs[i, 4]:
-                assert (half < 0).all(), "an unused child must have an inverted box"
+                assert (hi < lo).all(), "an unused child must have an inverted box"
                 assert refs[i, k] < 0, "an unused child must name a leaf (never a node: a ray of NaNs would loop)"
                 continue
-            lo, hi = centre - half, centre + half
             if box is not None and (np.any(lo < box[0] - 1e-3 * (1 + np.abs(box[0]))) or
                                     np.any(hi > box[1] + 1e-3 * (1 + np.abs(box[1])))):
                 outside += 1

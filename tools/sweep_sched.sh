@@ -1,9 +1,12 @@
 #!/bin/bash
-# GPU box: sweep of the decoupled scheduler's thresholds on the bench workload
-# (min_ready,leaf_min,blocked_min,regen_min per configuration; launches run alone).
-run() { timeout -k 10 120 python bench.py --steps 20 --warmup 3 --serial --no-cpu-baseline --no-configs 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('%.0f Mpaths/s kernel %.3f ms'%(d['value'], d['roofline']['kernel_ms_avg']))"; }
-for cfg in ${@:-"40,8,2,1" "36,8,2,1" "44,8,2,1" "48,8,2,1" "40,12,2,1" "40,6,2,1" "40,8,4,1" "40,8,2,8" "40,8,2,16" "44,12,4,8" "40,8,2,1"}; do
-  IFS=, read a b c d <<< "$cfg"
-  echo -n "min_ready=$a leaf_min=$b blocked_min=$c regen_min=$d : "
-  RT_AMD_MIN_READY=$a RT_AMD_LEAF_MIN=$b RT_AMD_BLOCKED_MIN=$c RT_AMD_REGEN_MIN=$d run || exit 1
-done
+# GPU box: sweep of the decoupled scheduler's thresholds on the pipelined bench.
+# usage: tools/sweep_sched.sh [scene] ["regen_min values"] ["min_ready values"] ["leaf_min values"]
+SCENE=${1:-bouncing_spheres}
+RG=${2:-"1 4 8 16"}
+MR=${3:-"32 40 48"}
+LM=${4:-"8"}
+STEPS=${STEPS:-100}; SPP=${SPP:-0}
+run() { timeout -k 10 170 python bench.py --steps $STEPS --spp $SPP --warmup 2 --repeats 3 --no-cpu-baseline --no-configs --scene $SCENE 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('%.0f Mpaths/s kernel %.3f ms'%(d['value'], d['roofline']['kernel_ms_avg']))"; }
+for rg in $RG; do for mr in $MR; do for lm in $LM; do
+  echo -n "regen_min $rg min_ready $mr leaf_min $lm : "; RT_AMD_REGEN_MIN=$rg RT_AMD_MIN_READY=$mr RT_AMD_LEAF_MIN=$lm run || exit 1
+done; done; done
