@@ -73,6 +73,12 @@ RT_HD f3 xyz(f4 v) { return mk(v.x, v.y, v.z); }
 #define RT_FEAT_IMAGE 1
 #define RT_FEAT_CHAIN 1
 #endif
+// True if the condition holds in any lane of the wave (host code: the one "lane" there is).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RT_WAVE_ANY(x) (__builtin_amdgcn_ballot_w64(x) != 0ull)
+#else
+#define RT_WAVE_ANY(x) (x)
+#endif
 #define RT_PI 3.1415926535897932385f
 #define RT_INF __builtin_huge_valf()
 
@@ -612,6 +618,15 @@ RT_HD bool box_hit_planes(float px, float py, float pz, float qx, float qy, floa
     float nz = __builtin_fmaf(pz, b.inv.z, b.oi.z), fz = __builtin_fmaf(qz, b.inv.z, b.oi.z);
     tn = fmaxf(fmaxf(fmaxf(nx, ny), nz), tmin);
     float tf = fminf(fminf(fminf(fx, fy), fz), tmax);
+#if defined(RT_WHATIF_MINMAX) && defined(__HIP_DEVICE_COMPILE__)
+    // What-if build: RT_WHATIF_MINMAX more half-rate instructions per box that change nothing.
+#pragma unroll
+    for (int k = 0; k < RT_WHATIF_MINMAX; k++) asm volatile("v_min_f32 %0, %0, %1" : "+v"(tf) : "v"(tmax));
+#endif
+#if defined(RT_WHATIF_FMA) && defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int k = 0; k < RT_WHATIF_FMA; k++) asm volatile("v_fma_f32 %0, %0, 1.0, 0" : "+v"(tf));
+#endif
     float tf_wide = __builtin_fmaf(tf, 1.0f + 1.9073486328125e-6f, b.e2); // (see box_hit)
     return tn <= tf_wide;
 }
@@ -790,6 +805,19 @@ template <bool COUNT> RT_HD NodePlanes node_planes_lds(const f4 *node, const Box
     r.pz = *(const RT_AS_LDS f4 *)(n + 64 + b.sz), r.qz = *(const RT_AS_LDS f4 *)(n + 64 + (16 - b.sz));
     r.refs = *(const RT_AS_LDS f4 *)(n + 96);
     r.n_children = COUNT ? *(const RT_AS_LDS int *)(n + 112) : 0;
+#if defined(RT_WHATIF_LDS_READS) && defined(__HIP_DEVICE_COMPILE__)
+    // What-if build (tools/whatif.sh): RT_WHATIF_LDS_READS more 16-byte LDS reads per node step, of
+    // the neighbouring node, folded into a value that never changes anything.
+    {
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < RT_WHATIF_LDS_READS; k++) {
+            const f4 x = *(const RT_AS_LDS f4 *)(n + 144 + 16 * k + b.sx);
+            acc += x.x;
+        }
+        if (acc == 1.2345e-33f) r.refs.x = 0.0f;
+    }
+#endif
     return r;
 }
 template <bool COUNT> RT_HD NodePlanes node_planes_global(const f4 *node, const BoxRay &b) {
@@ -1116,35 +1144,52 @@ RT_HD bool shade_hit(const DevScene &sc, const SceneView &vw, int slot, PathStat
         ps.L = ps.L + ps.beta * col;
         return false;
     }
+    // The three scattering materials share what is expensive in them: every one draws a first
+    // random number (z of the random unit vector of lambertian and metal, material.h:30-60; the
+    // number the reflectance is compared with for a dielectric, material.h:86), metal and
+    // dielectric normalise one vector each (the reflected direction, material.h:56; the incoming
+    // one, material.h:77) and each takes one square root (vec3.h:147-148's normalisation as
+    // sample_unit_vector restates it; sin_theta, material.h:80).  A wave that shades all three
+    // kinds at once (nearly every wave of a scene that has them) runs those once for all its
+    // lanes instead of once per kind; each lane gets the value its own material's code computes.
+    const bool diel = mat == RT_MAT_DIELECTRIC, lamb = mat == RT_MAT_LAMBERTIAN;
+    const float u1 = rng_next(ps.rng);
+    f3 vu = mk(0.0f, 0.0f, 0.0f);
+    if (RT_WAVE_ANY(!lamb)) { // (scenes of lambertian surfaces only skip this as a wave)
+        const f3 reflected = reflect(ps.ray.d, s.n);
+        vu = unit(diel ? ps.ray.d : reflected);
+    }
+    const float cos_theta = fminf(dot(-vu, s.n), 1.0f);
+    const float z = 1.0f - 2.0f * u1;
+    const float root = sqrtf(diel ? 1.0f - cos_theta * cos_theta : fmaxf(0.0f, 1.0f - z * z));
     f3 dir;
-    if (mat == RT_MAT_DIELECTRIC) { // material.h:72-90
+    if (diel) { // material.h:72-90
         RT_COUNT(sh2);
         // the record holds {1/ri, r0 seen from outside, r0 seen from inside, ri}: the host has done
         // the divisions of material.h:76 and 99, in the same fp32 arithmetic
         float ri = s.front ? rf.x : rf.w;
         float r0 = s.front ? rf.y : rf.z;
         col = mk(1.0f, 1.0f, 1.0f);
-        f3 unit_direction = unit(ps.ray.d);
-        float cos_theta = fminf(dot(-unit_direction, s.n), 1.0f);
-        float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+        const f3 unit_direction = vu;
+        const float sin_theta = root;
         bool cannot_refract = ri * sin_theta > 1.0f;
-        float xi = rng_next(ps.rng);
-        if (cannot_refract || schlick_r0(cos_theta, r0) > xi)
+        if (cannot_refract || schlick_r0(cos_theta, r0) > u1)
             dir = reflect(unit_direction, s.n);
         else
             dir = refract(unit_direction, s.n, ri);
     } else {
         // lambertian (material.h:30-42) and metal (material.h:53-60) both draw one
         // random unit vector
-        f3 rv = sample_unit_vector(ps.rng);
-        if (mat == RT_MAT_LAMBERTIAN) {
+        float sn, cs;
+        sincos_2pi(rng_next(ps.rng), sn, cs);
+        const f3 rv = mk(root * cs, root * sn, z);
+        if (lamb) {
             RT_COUNT(sh0);
             dir = s.n + rv;
             if (fabsf(dir.x) < 1e-8f && fabsf(dir.y) < 1e-8f && fabsf(dir.z) < 1e-8f) dir = s.n;
         } else {
             RT_COUNT(sh1);
-            f3 reflected = reflect(ps.ray.d, s.n);
-            dir = unit(reflected) + (rf.w * rv);
+            dir = vu + (rf.w * rv);
             if (!(dot(dir, s.n) > 0)) return false; // absorbed: contributes nothing
         }
     }
