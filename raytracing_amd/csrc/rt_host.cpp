@@ -581,7 +581,7 @@ int ensure_wavefront(rt_scene *s, unsigned n_slots) {
     for (int k = 0; k < 5; k++) w.q_mat[k] = (int *)take(n * 4);
     w.q_free = (int *)take(n * 4);
     w.cnt = (unsigned *)take(64);
-    if (!s->wf_host_cnt) RT_HIP(hipHostMalloc((void **)&s->wf_host_cnt, 64, hipHostMallocDefault));
+    if (!s->wf_host_cnt) RT_HIP(hipHostMalloc((void **)&s->wf_host_cnt, 2 * 16 * sizeof(unsigned), hipHostMallocDefault));
     s->wf_slots = n_slots;
     return RT_OK;
 }

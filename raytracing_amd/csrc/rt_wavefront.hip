@@ -3,7 +3,6 @@
 // Same integrator, sampler and per-ray code (rt_core.h) as the megakernel, organised as
 // separate kernels around queues in HBM instead of one persistent kernel:
 //
-//   wf_prep      1 thread   : rotates the queue counters for the round
 //   wf_generate  1 lane/slot: starts new camera paths in the path slots freed last round
 //   wf_trace     persistent : closest hit for every queued ray (geometry staged in LDS)
 //   wf_classify  1 lane/ray : appends each traced ray to the queue of the material it hit (or
@@ -11,10 +10,11 @@
 //   wf_shade     1 lane/hit : walks the material queues back to back, so that a wave shades one
 //                             material; continuing paths are queued for the next round,
 //                             finished ones write their radiance record and free their slot
+//   wf_prep      1 thread   : rotates the queue counters for the next round
 //
 // It exists to be compared with the megakernel (same images, see tests/test_gpu_wavefront.py):
 // coherent shading and a trace kernel free of shading registers, paid for with ~200 bytes of
-// HBM traffic per ray and six launches per bounce.
+// HBM traffic per ray and five launches per bounce.
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
@@ -78,7 +78,13 @@ __device__ __forceinline__ void block_push(int *const (&q)[NQ], unsigned *counte
     __syncthreads();
 }
 
-__global__ void wf_prep(unsigned *cnt, unsigned total_paths) {
+// Book-keeping between two rounds, by one thread: the paths the generator started in the round
+// that ends are taken off the pool, the slots its shading freed are credited to the finished
+// paths, and the next round's queue is laid out (carried-over rays first, new paths behind).
+// (A ticket taken by every workgroup of the shading kernel, so that the last one could do this, was
+// measured slower than this one-thread launch: 2048 atomics on one address per round.)
+__device__ __forceinline__ void prep_round(unsigned *cnt, unsigned total_paths) {
+    cnt[C_POOL] += cnt[C_GEN_COUNT];
     cnt[C_DONE] += cnt[C_FREE];
     unsigned carried = cnt[C_TRACE_NEXT];
     unsigned n_free = cnt[C_FREE_SNAP] = cnt[C_FREE];
@@ -91,9 +97,10 @@ __global__ void wf_prep(unsigned *cnt, unsigned total_paths) {
     cnt[C_FREE] = 0;
     for (int k = 0; k < N_QUEUES; k++) cnt[C_Q0 + k] = 0;
 }
+__global__ void wf_prep(unsigned *cnt, unsigned total_paths) { prep_round(cnt, total_paths); }
 
-// Thread i starts path number pool + i in the i-th free slot.  No atomics: wf_prep has
-// already reserved the queue space and wf_advance moves the pool position afterwards.
+// Thread i starts path number pool + i in the i-th free slot.  No atomics: prep_round has
+// already reserved the queue space and moves the pool position afterwards.
 // Free slots beyond the paths that are left are dropped (nothing will need them again).
 __global__ void __launch_bounds__(256)
 wf_generate(DevCamera cam, RenderParams rp, WfBuffers wf, int *q_trace_cur) {
@@ -115,8 +122,6 @@ wf_generate(DevCamera cam, RenderParams rp, WfBuffers wf, int *q_trace_cur) {
     wf.aux[slot] = i4{0, -1, (int)pixel, (int)s_local};
     q_trace_cur[wf.cnt[C_GEN_BASE] + i] = slot;
 }
-
-__global__ void wf_advance(unsigned *cnt) { cnt[C_POOL] += cnt[C_GEN_COUNT]; }
 
 // Persistent: one workgroup per CU stages the geometry into LDS once per launch; its waves
 // take batches of 64 queued rays, wave w the batches w, w + (waves of the grid), ...  Linear
@@ -295,14 +300,15 @@ wf_shade(DevScene sc, DevCamera cam, RenderParams rp, WfBuffers wf, int *q_trace
     }
 }
 
-__global__ void wf_init(WfBuffers wf, unsigned n_slots) {
+__global__ void wf_init(WfBuffers wf, unsigned n_slots, unsigned total_paths) {
     unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_slots) wf.q_free[i] = (int)i;
     if (i == 0) {
         for (int k = 0; k < 16; k++) wf.cnt[k] = 0;
         wf.cnt[C_FREE] = n_slots;
-        // wf_prep credits the freed slots of the previous round to the finished paths
+        // prep_round credits the freed slots of the previous round to the finished paths
         wf.cnt[C_DONE] = 0u - n_slots;
+        prep_round(wf.cnt, total_paths);
     }
 }
 
@@ -324,22 +330,31 @@ hipError_t set_wavefront_lds_limit(int bytes) {
 }
 
 // Renders one launch chunk (rp.sample_count samples of every pixel) into rp.stage.
-// `host_cnt` is pinned host memory for polling the finished-path counter.
+// `host_cnt` is pinned host memory (2 x 16 words) for looking at the finished-path counter.  Rounds
+// are enqueued eight at a time, and the next eight go out before the host looks at the counters
+// the previous eight left behind, so the GPU never waits for that look; the rounds that turn out
+// to be superfluous find empty queues and end at once.
 hipError_t render_wavefront(const DevScene &sc, const DevCamera &cam, const RenderParams &rp, const WfBuffers &wf,
                             unsigned n_slots, const LaunchGeom &lg, unsigned *host_cnt, hipStream_t stream,
                             int *rounds_out) {
     const unsigned total = (unsigned)rp.n_pixels * (unsigned)rp.sample_count;
     const int slot_grid = (int)((n_slots + 255) / 256);
     const int big_grid = (int)((n_slots + 1023) / 1024);
-    hipLaunchKernelGGL(wf_init, dim3(slot_grid), dim3(256), 0, stream, wf, n_slots);
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    hipError_t e = hipEventCreateWithFlags(&ev[0], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[1], hipEventDisableTiming);
+    if (e != hipSuccess) {
+        if (ev[0]) hipEventDestroy(ev[0]);
+        return e;
+    }
+    hipLaunchKernelGGL(wf_init, dim3(slot_grid), dim3(256), 0, stream, wf, n_slots, total);
     int rounds = 0;
-    for (;;) {
-        // a batch of rounds between two looks at the counters; a round advances every path by one bounce
+    // a batch of rounds, then a copy of the counters into half `b` of host_cnt and an event behind it;
+    // a round advances every path by one bounce
+    auto enqueue_batch = [&](int b) -> hipError_t {
         for (int k = 0; k < 8; k++, rounds++) {
             int *cur = wf.q_trace[rounds & 1], *next = wf.q_trace[(rounds + 1) & 1];
-            hipLaunchKernelGGL(wf_prep, dim3(1), dim3(1), 0, stream, wf.cnt, total);
             hipLaunchKernelGGL(wf_generate, dim3(slot_grid), dim3(256), 0, stream, cam, rp, wf, cur);
-            hipLaunchKernelGGL(wf_advance, dim3(1), dim3(1), 0, stream, wf.cnt);
             if (sc.traversal == TRAV_LINEAR) {
                 if (lg.lds_scene)
                     hipLaunchKernelGGL((wf_trace<TRAV_LINEAR, true>), dim3(lg.grid), dim3(lg.block), lg.lds_bytes, stream, sc, wf, cur, rp);
@@ -353,17 +368,31 @@ hipError_t render_wavefront(const DevScene &sc, const DevCamera &cam, const Rend
             }
             hipLaunchKernelGGL(wf_classify, dim3(big_grid), dim3(1024), 0, stream, wf, cur);
             hipLaunchKernelGGL(wf_shade, dim3(big_grid), dim3(1024), 0, stream, sc, cam, rp, wf, next);
+            hipLaunchKernelGGL(wf_prep, dim3(1), dim3(1), 0, stream, wf.cnt, total);
         }
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return e;
-        e = hipMemcpyAsync(host_cnt, wf.cnt, 16 * sizeof(unsigned), hipMemcpyDeviceToHost, stream);
-        if (e != hipSuccess) return e;
-        e = hipStreamSynchronize(stream);
-        if (e != hipSuccess) return e;
-        if (host_cnt[C_DONE] + host_cnt[C_FREE] >= total) break; // C_FREE: finished in the last round
-        if (rounds > 100000) return hipErrorUnknown; // cannot happen: every round retires or advances paths
+        hipError_t r = hipGetLastError();
+        if (r == hipSuccess) r = hipMemcpyAsync(host_cnt + 16 * b, wf.cnt, 16 * sizeof(unsigned), hipMemcpyDeviceToHost, stream);
+        if (r == hipSuccess) r = hipEventRecord(ev[b], stream);
+        return r;
+    };
+    int rounds_needed = 0;
+    e = enqueue_batch(0);
+    for (int b = 0; e == hipSuccess; b ^= 1) {
+        const int rounds_before = rounds;
+        e = enqueue_batch(b ^ 1);
+        if (e == hipSuccess) e = hipEventSynchronize(ev[b]);
+        if (e != hipSuccess) break;
+        // (the round's closing book-keeping has already credited the last round's paths)
+        if (host_cnt[16 * b + C_DONE] + host_cnt[16 * b + C_FREE] >= total) {
+            rounds_needed = rounds_before;
+            break;
+        }
+        if (rounds > 100000) e = hipErrorUnknown; // cannot happen: every round retires or advances paths
     }
-    if (rounds_out) *rounds_out = rounds;
+    hipEventDestroy(ev[0]);
+    hipEventDestroy(ev[1]);
+    if (e != hipSuccess) return e;
+    if (rounds_out) *rounds_out = rounds_needed;
     return hipSuccess;
 }
 
