@@ -1018,8 +1018,11 @@ RT_HD float perlin_noise(const DevPerlin &pn, f3 p) {
                 int idx = (di ? pi1 : pi0) ^ (dj ? pj1 : pj0) ^ (dk ? pk1 : pk0);
                 f3 c = xyz(pn.randvec[idx]);
                 f3 wv = mk(u - di, v - dj, w - dk);
-                accum += (di * uu + (1 - di) * (1 - uu)) * (dj * vv + (1 - dj) * (1 - vv)) *
-                         (dk * ww + (1 - dk) * (1 - ww)) * dot(c, wv);
+                // perlin.h:75-77 weighs a corner with (i*uu + (1-i)*(1-uu)) ... for i, j, k in {0, 1}: one
+                // of the two products is 0 * x = 0 and the other 1 * y = y (uu, vv, ww lie in [0, 1]),
+                // and y + 0 = y, so each factor is uu or 1 - uu bit for bit; the compiler may not fold
+                // that itself (0 * x is not 0 for every x), so it is written out
+                accum += (di ? uu : 1 - uu) * (dj ? vv : 1 - vv) * (dk ? ww : 1 - ww) * dot(c, wv);
             }
     return accum;
 }

@@ -604,7 +604,7 @@ Tunables read_tunables(bool lds_scene) {
     t.tail_blocks = env_int("RT_AMD_TAIL_BLOCKS", lds_scene ? 8 : 16);
     t.unit_order = env_int("RT_AMD_UNIT_ORDER", 1);
     t.strip_order = env_int("RT_AMD_STRIP_ORDER", lds_scene ? 1 : 0);
-    t.min_ready = std::max(1, std::min(64, env_int("RT_AMD_MIN_READY", 40)));
+    t.min_ready = std::max(1, std::min(64, env_int("RT_AMD_MIN_READY", 48)));
     t.leaf_min = std::max(1, std::min(64, env_int("RT_AMD_LEAF_MIN", 8)));
     t.blocked_min = std::max(1, std::min(64, env_int("RT_AMD_BLOCKED_MIN", 2)));
     t.regen_min = std::max(1, std::min(64, env_int("RT_AMD_REGEN_MIN", 1)));

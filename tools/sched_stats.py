@@ -4,7 +4,14 @@ from raytracing_amd import abi, binding
 G = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 scene = sys.argv[1] if len(sys.argv) > 1 else "bouncing_spheres"
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 100
-arrays = abi.SceneArrays.load(f"{G}/{scene}.rtscene"); cam, _ = abi.load_camera_file(f"{G}/{scene}.cam")
+if scene == "synth1m":  # the 10^6-primitive scene comes from the scene program (as in bench.py)
+    import subprocess
+    out = "/tmp/sched_synth1m.rtscene"
+    prog = os.path.join(os.path.dirname(G), "..", "examples", "bin", "rt_scenes")
+    subprocess.run([prog, "synth1m", "--half", "500", "--dump", out], check=True, capture_output=True)
+    arrays = abi.SceneArrays.load(out); cam, _ = abi.load_camera_file(out + ".cam")
+else:
+    arrays = abi.SceneArrays.load(f"{G}/{scene}.rtscene"); cam, _ = abi.load_camera_file(f"{G}/{scene}.cam")
 sc = binding.Scene(arrays)
 acc, st = sc.render(cam, spp, counters=True)
 acc, st0 = sc.render(cam, spp)
