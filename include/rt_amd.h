@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RT_AMD_ABI_VERSION 3
+#define RT_AMD_ABI_VERSION 4
 
 /* ---- error codes ------------------------------------------------------- */
 enum {
@@ -118,6 +118,24 @@ typedef struct rt_group {
     int32_t reserved;
 } rt_group;
 
+/* A sub-scene placed in the world several times: what the reference builds when one hittable
+ * (a list, a bvh_node, a primitive) is handed to several instance wrappers (hittable.h:51-344:
+ * translate / rotate_y / rotate_xyz / scaling keep a shared_ptr to the object they move).
+ * prims [first_prim, first_prim + n_prims) are the sub-scene, in its own space (each may still
+ * carry wrappers of its own in `xform`); they are not part of the world by themselves.  Instance i
+ * puts them into the world under the wrapper chain `xform` (-1: as they are).  The ranges of two
+ * instances are either the same or disjoint.  The library keeps one copy of the primitives and
+ * one tree per distinct range and a tree over the instances (a two-level BVH): memory and build
+ * time do not grow with the number of instances.  Results equal those of the same scene with
+ * every instance written out as primitives (loose primitives first, in their order, then the
+ * instances in theirs: that order decides ties between equal hits); rt_hit.prim names the
+ * primitive of the sub-scene. */
+typedef struct rt_instance {
+    int32_t first_prim, n_prims;
+    int32_t xform; /* index into chains[], -1 = none */
+    int32_t reserved;
+} rt_instance;
+
 typedef struct rt_scene_desc {
     uint32_t abi_version; /* RT_AMD_ABI_VERSION */
     int32_t n_prims;
@@ -138,6 +156,8 @@ typedef struct rt_scene_desc {
     const rt_xform_op *xform_ops;
     int32_t n_chains;
     const rt_xform_chain *chains;
+    int32_t n_instances; /* 0: every primitive is part of the world */
+    const rt_instance *instances;
 } rt_scene_desc;
 
 /* ---- camera (camera.h:15-29 public fields, same defaults expected) ------ */

@@ -4,7 +4,7 @@
  * A .rtscene file is a flat dump of an rt_scene_desc (rt_amd.h):
  *   char     magic[8] = "RTSCENE1"
  *   uint64_t counts[10] = { n_prims, n_groups, n_materials, n_textures, n_perlins,
- *                           n_images, n_texel_bytes, n_xform_ops, n_chains, 0 }
+ *                           n_images, n_texel_bytes, n_xform_ops, n_chains, n_instances }
  *   then the arrays in that order, each padded to a multiple of 8 bytes.
  * Shared by the library, the CPU oracle and the reference harness so that all
  * three exchange scenes through one format.
@@ -38,7 +38,7 @@ inline int save(const rt_scene_desc *d, const char *path) {
                            (uint64_t)d->n_materials, (uint64_t)d->n_textures,
                            (uint64_t)d->n_perlins,   (uint64_t)d->n_images,
                            d->n_texel_bytes,         (uint64_t)d->n_xform_ops,
-                           (uint64_t)d->n_chains,    0};
+                           (uint64_t)d->n_chains,    (uint64_t)d->n_instances};
     bool ok = fwrite(kMagic, 1, 8, f) == 8 && fwrite(counts, sizeof(uint64_t), 10, f) == 10;
     ok = ok && write_block(f, d->prims, sizeof(rt_prim) * d->n_prims);
     ok = ok && write_block(f, d->groups, sizeof(rt_group) * d->n_groups);
@@ -49,6 +49,7 @@ inline int save(const rt_scene_desc *d, const char *path) {
     ok = ok && write_block(f, d->texels, d->n_texel_bytes);
     ok = ok && write_block(f, d->xform_ops, sizeof(rt_xform_op) * d->n_xform_ops);
     ok = ok && write_block(f, d->chains, sizeof(rt_xform_chain) * d->n_chains);
+    ok = ok && write_block(f, d->instances, sizeof(rt_instance) * d->n_instances);
     ok = (fclose(f) == 0) && ok;
     return ok ? RT_OK : RT_ERR_IO;
 }
@@ -67,9 +68,10 @@ inline rt_scene_desc *load(const char *path) {
     }
     /* the counts come from the file: every element count must fit the descriptor's int32
      * fields, no size may wrap, and the arrays together must be what the file actually holds */
-    static const size_t elem[9] = {sizeof(rt_prim),     sizeof(rt_group),   sizeof(rt_material),
-                                   sizeof(rt_texture),  sizeof(rt_perlin),  sizeof(rt_image),
-                                   1,                   sizeof(rt_xform_op), sizeof(rt_xform_chain)};
+    static const size_t elem[10] = {sizeof(rt_prim),     sizeof(rt_group),    sizeof(rt_material),
+                                    sizeof(rt_texture),  sizeof(rt_perlin),   sizeof(rt_image),
+                                    1,                   sizeof(rt_xform_op), sizeof(rt_xform_chain),
+                                    sizeof(rt_instance)};
     long here = ftell(f);
     if (here < 0 || fseek(f, 0, SEEK_END) != 0) {
         fclose(f);
@@ -81,9 +83,9 @@ inline rt_scene_desc *load(const char *path) {
         return nullptr;
     }
     const uint64_t file_payload = (uint64_t)(end - here);
-    size_t sz[9];
+    size_t sz[10];
     uint64_t sum = 0;
-    for (int i = 0; i < 9; i++) {
+    for (int i = 0; i < 10; i++) {
         const uint64_t limit = i == 6 ? file_payload : (uint64_t)0x7fffffff;
         if (c[i] > limit || c[i] > file_payload / elem[i]) { /* (also rules out a wrapping product) */
             fclose(f);
@@ -112,8 +114,8 @@ inline rt_scene_desc *load(const char *path) {
     rt_scene_desc *d = (rt_scene_desc *)blk;
     memset(d, 0, sizeof(*d));
     char *p = blk + pad8(sizeof(rt_scene_desc));
-    const void *ptr[9];
-    for (int i = 0; i < 9; i++) {
+    const void *ptr[10];
+    for (int i = 0; i < 10; i++) {
         ptr[i] = sz[i] ? p : nullptr;
         p += pad8(sz[i]);
     }
@@ -136,6 +138,8 @@ inline rt_scene_desc *load(const char *path) {
     d->xform_ops = (const rt_xform_op *)ptr[7];
     d->n_chains = (int32_t)c[8];
     d->chains = (const rt_xform_chain *)ptr[8];
+    d->n_instances = (int32_t)c[9];
+    d->instances = (const rt_instance *)ptr[9];
     return d;
 }
 

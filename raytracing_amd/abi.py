@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-RT_AMD_ABI_VERSION = 3
+RT_AMD_ABI_VERSION = 4
 
 RT_OK, RT_ERR_ARG, RT_ERR_HIP, RT_ERR_UNSUPPORTED, RT_ERR_IO = 0, -1, -2, -3, -4
 RT_PRIM_SPHERE, RT_PRIM_QUAD = 0, 1
@@ -35,6 +35,7 @@ IMAGE_DT = np.dtype([("width", "<i4"), ("height", "<i4"), ("offset", "<u8")])
 XFORM_OP_DT = np.dtype([("type", "<i4"), ("p", "<f4", 3)])
 CHAIN_DT = np.dtype([("first_op", "<i4"), ("n_ops", "<i4")])
 GROUP_DT = np.dtype([("kind", "<i4"), ("first_prim", "<i4"), ("n_prims", "<i4"), ("reserved", "<i4")])
+INSTANCE_DT = np.dtype([("first_prim", "<i4"), ("n_prims", "<i4"), ("xform", "<i4"), ("reserved", "<i4")])
 RAY_DT = np.dtype([("orig", "<f4", 3), ("dir", "<f4", 3), ("tm", "<f4")])
 HIT_DT = np.dtype([("prim", "<i4"), ("front_face", "<i4"), ("t", "<f4"), ("p", "<f4", 3),
                    ("normal", "<f4", 3), ("u", "<f4"), ("v", "<f4")])
@@ -53,7 +54,8 @@ class SceneDesc(C.Structure):
                 ("n_images", C.c_int32), ("images", C.c_void_p),
                 ("n_texel_bytes", C.c_uint64), ("texels", C.c_void_p),
                 ("n_xform_ops", C.c_int32), ("xform_ops", C.c_void_p),
-                ("n_chains", C.c_int32), ("chains", C.c_void_p)]
+                ("n_chains", C.c_int32), ("chains", C.c_void_p),
+                ("n_instances", C.c_int32), ("instances", C.c_void_p)]
 
 
 class CameraDesc(C.Structure):
@@ -110,7 +112,8 @@ class SceneArrays:
 
     FIELDS = [("prims", PRIM_DT), ("groups", GROUP_DT), ("materials", MATERIAL_DT),
               ("textures", TEXTURE_DT), ("perlins", PERLIN_DT), ("images", IMAGE_DT),
-              ("texels", np.dtype("u1")), ("xform_ops", XFORM_OP_DT), ("chains", CHAIN_DT)]
+              ("texels", np.dtype("u1")), ("xform_ops", XFORM_OP_DT), ("chains", CHAIN_DT),
+              ("instances", INSTANCE_DT)]
 
     def __init__(self, **arrays):
         for name, dt in self.FIELDS:
@@ -136,6 +139,7 @@ class SceneArrays:
         d.n_texel_bytes, d.texels = self.texels.size, ptr(self.texels)
         d.n_xform_ops, d.xform_ops = len(self.xform_ops), ptr(self.xform_ops)
         d.n_chains, d.chains = len(self.chains), ptr(self.chains)
+        d.n_instances, d.instances = len(self.instances), ptr(self.instances)
         return d
 
     @classmethod
@@ -148,7 +152,7 @@ class SceneArrays:
         counts = np.frombuffer(blob, "<u8", 10, 8)
         off = 8 + 80
         arrays = {}
-        for (name, dt), n in zip(cls.FIELDS, counts[:9]):
+        for (name, dt), n in zip(cls.FIELDS, counts[:10]):
             nbytes = int(n) * dt.itemsize
             arrays[name] = np.frombuffer(blob, dt, int(n), off).copy()
             off += (nbytes + 7) & ~7

@@ -67,11 +67,19 @@ RT_HD f3 xyz(f4 v) { return mk(v.x, v.y, v.z); }
 #define RT_FEAT_NOISE 0
 #define RT_FEAT_IMAGE 0
 #define RT_FEAT_CHAIN 0
+#define RT_FEAT_INSTANCE 0
 #else
 #define RT_FEAT_QUAD 1
 #define RT_FEAT_NOISE 1
 #define RT_FEAT_IMAGE 1
 #define RT_FEAT_CHAIN 1
+// the two-level traversal of scenes with instances: device code has it only in the build made for
+// such scenes (RT_INST): its checks cost the 10^6-primitive scene 3.5 % when they sat in every kernel
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RT_INST)
+#define RT_FEAT_INSTANCE 0
+#else
+#define RT_FEAT_INSTANCE 1
+#endif
 #endif
 // True if the condition holds in any lane of the wave (host code: the one "lane" there is).
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -154,6 +162,11 @@ struct DevScene {
     const DevPerlin *perlins;
     const rt_image *images;
     const uint8_t *texels;
+    // two-level scenes: per instance {root reference of the sub-scene's tree, wrapper chain (-1: none),
+    // offset of its primitives' ids among all primitives of the world, -}.  Instance k is the leaf
+    // "slot" n_slots + k of the top tree; slot n_slots + n_inst marks the end of a visit on the stack.
+    const i4 *inst;
+    int n_inst;
     int n_slots;
     int n_nodes;
     int n_textures;
@@ -497,7 +510,8 @@ RT_HD size_t slot_words(const DevScene &sc, int slot) {
 
 struct TraceHit {
     float t;
-    int slot; // -1: miss
+    int slot;      // -1: miss
+    int inst = -1; // the instance the primitive was hit in (-1: a primitive of the world itself)
 };
 
 // hittable_list::hit (hittable_list.h:29-43): scan in test order with a shrinking
@@ -689,6 +703,8 @@ struct Trav {
     int sp; // entries on the stack, times the stride
     bool best_is_quad;
     float dd; // |d|^2 of the world-space ray
+    int cur_inst;  // the instance whose sub-scene is being walked (-1: the world's own tree)
+    int best_inst; // the instance of the closest hit so far
 };
 RT_HD void trav_begin(Trav &tv, const Ray &r, float tmax) {
     tv.br = make_box_ray(r);
@@ -698,6 +714,8 @@ RT_HD void trav_begin(Trav &tv, const Ray &r, float tmax) {
     tv.best_is_quad = false;
     tv.ref = 0; // root
     tv.sp = 0;
+    tv.cur_inst = -1;
+    tv.best_inst = -1;
 }
 
 // A stack entry is a sort key: the child's entry parameter in the high bits (a positive float
@@ -891,6 +909,18 @@ RT_HD void trav_test_leaf(Trav &tv, int leaf_ref, const DevScene &sc, const Scen
     // parameter there: the direction is transformed, not normalised)
     f3 o = r.o, d = r.d;
     float dd = tv.dd;
+    int id_off = 0, best_id_off = 0;
+    if (RT_FEAT_INSTANCE && sc.n_inst > 0) { // inside an instance: its wrappers first (the outer ones)
+        if (tv.cur_inst >= 0) {
+            const i4 in = sc.inst[tv.cur_inst];
+            id_off = in.z;
+            if (in.y >= 0) {
+                chain_ray_to_object(sc, in.y, o, d);
+                dd = len2(d);
+            }
+        }
+        if (tv.best_inst >= 0) best_id_off = sc.inst[tv.best_inst].z;
+    }
     if (RT_FEAT_CHAIN && sc.n_chains > 0) {
         int chain = v.rec_i[s].z;
         if (chain >= 0) {
@@ -911,15 +941,53 @@ RT_HD void trav_test_leaf(Trav &tv, int leaf_ref, const DevScene &sc, const Scen
     if (h) {
         bool take = t < tv.best_t;
         if (!take) { // t == best_t: rare
-            int cid = v.rec_i[s].w;
-            int bid = tv.best_slot >= 0 ? v.rec_i[tv.best_slot].w : -1;
+            int cid = v.rec_i[s].w + id_off;
+            int bid = tv.best_slot >= 0 ? v.rec_i[tv.best_slot].w + best_id_off : -1;
             take = tie_prefers_candidate(cid, is_quad, bid, tv.best_is_quad);
         }
         if (take) {
             tv.best_t = t;
             tv.best_slot = s;
             tv.best_is_quad = is_quad;
+            if (RT_FEAT_INSTANCE) tv.best_inst = tv.cur_inst;
         }
+    }
+}
+
+// Two-level scenes.  A leaf whose slot lies beyond the primitives is not a primitive: slot
+// n_slots + k enters instance k (the ray goes into the sub-scene's space through the instance's
+// wrappers, a mark is left on the stack, and the walk goes on at the root of the sub-scene's
+// tree; t is the same parameter in both spaces, so the closest hit so far keeps culling), and
+// slot n_slots + n_inst is that mark coming off the stack again: back to the world's space.
+// Such a leaf is a barrier: a lane must not walk on past it (the boxes ahead are in the other
+// space) before it has been dealt with.
+RT_HD bool trav_is_barrier(const DevScene &sc, int ref) {
+    return RT_FEAT_INSTANCE && ref < 0 && ref != RT_TRAV_DONE && ((~ref) >> 1) >= sc.n_slots;
+}
+template <class ST, bool SPILL>
+RT_HD void trav_barrier(Trav &tv, const DevScene &sc, const Ray &world, const ST &st) {
+    typedef typename ST::elem T;
+    const int k = ((~tv.ref) >> 1) - sc.n_slots;
+    if (k < sc.n_inst) { // enter
+        const i4 in = sc.inst[k];
+        const int mark = ~((sc.n_slots + sc.n_inst) << 1);
+        // (a stack entry is a key whose low ref_bits bits are the reference; the distance bits of the
+        // mark do not matter: nothing is sorted against it)
+        const unsigned lo = sc.ref_bits >= 32 ? 0xffffffffu : (1u << sc.ref_bits) - 1u;
+        if (!SPILL || tv.sp < st.lds_end)
+            st.lds[tv.sp] = (T)((unsigned)mark & lo);
+        else
+            st.spill[tv.sp - st.lds_end] = (int)((unsigned)mark & lo);
+        tv.sp += st.stride();
+        tv.cur_inst = k;
+        Ray r = world;
+        if (in.y >= 0) chain_ray_to_object(sc, in.y, r.o, r.d);
+        tv.br = make_box_ray(r);
+        tv.ref = in.x;
+    } else { // leave
+        tv.cur_inst = -1;
+        tv.br = make_box_ray(world);
+        trav_pop<ST, SPILL>(tv, st, sc.ref_bits);
     }
 }
 
@@ -932,6 +1000,8 @@ RT_HD TraceHit trace_bvh(const DevScene &sc, const SceneView &v, const Ray &r, f
     while (tv.ref != RT_TRAV_DONE) {
         if (tv.ref >= 0) {
             trav_inner<COUNT, ST, false, SPILL, NODE_F4>(tv, v.nodes, tmin, st, sc.ref_bits, cn);
+        } else if (RT_FEAT_INSTANCE && sc.n_inst > 0 && trav_is_barrier(sc, tv.ref)) {
+            trav_barrier<ST, SPILL>(tv, sc, r, st);
         } else {
             trav_test_leaf<COUNT>(tv, tv.ref, sc, v, r, tmin, cn);
             trav_pop<ST, SPILL>(tv, st, sc.ref_bits);
@@ -940,6 +1010,7 @@ RT_HD TraceHit trace_bvh(const DevScene &sc, const SceneView &v, const Ray &r, f
     TraceHit best;
     best.t = tv.best_t;
     best.slot = tv.best_slot;
+    if (RT_FEAT_INSTANCE) best.inst = tv.best_inst;
     return best;
 }
 
@@ -966,6 +1037,9 @@ RT_HD Surf surface_at(const DevScene &sc, const SceneView &vw, const Ray &r, Tra
     i4 m = vw.rec_i[h.slot];
     s.rec = m;
     f3 o = r.o, d = r.d;
+    int inst_chain = -1; // the wrappers of the instance the primitive was hit in: the outermost ones
+    if (RT_FEAT_INSTANCE && sc.n_inst > 0 && h.inst >= 0) inst_chain = sc.inst[h.inst].y;
+    if (RT_FEAT_INSTANCE && inst_chain >= 0) chain_ray_to_object(sc, inst_chain, o, d);
     if (RT_FEAT_CHAIN && m.z >= 0) chain_ray_to_object(sc, m.z, o, d);
     const f4 *g = vw.slots + slot_words(sc, h.slot);
     f3 p = o + h.t * d; // ray.h:20
@@ -990,6 +1064,7 @@ RT_HD Surf surface_at(const DevScene &sc, const SceneView &vw, const Ray &r, Tra
     s.front = dot(d, outward) < 0; // hittable.h:20-25
     f3 n = s.front ? outward : -outward;
     if (RT_FEAT_CHAIN && m.z >= 0) chain_hit_to_world(sc, m.z, p, n);
+    if (RT_FEAT_INSTANCE && inst_chain >= 0) chain_hit_to_world(sc, inst_chain, p, n);
     s.p = p;
     s.n = n;
     return s;

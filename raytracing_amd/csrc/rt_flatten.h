@@ -684,7 +684,44 @@ struct HostScene {
     bool any_chain = false; // some primitive sits inside instance wrappers
     bool external_nodes = false; // the binary tree came from the external (device) builder
     int n_bin_nodes = 0;         // nodes of the binary tree the wide one was collapsed from
+    // two-level scenes (rt_instance): per instance {root reference of its sub-scene's tree, wrapper
+    // chain, what to add to a primitive's id to order it among all primitives of the world, -}
+    std::vector<i4> inst;
 };
+
+// Adds node_base to the inner references of wide nodes [first, first + count) and maps their
+// leaf slots through leaf_slot (joining trees that were built apart).
+template <class F>
+inline void relocate_wide(std::vector<f4> &nodes, size_t first, size_t count, int node_base, F leaf_slot) {
+    for (size_t i = first; i < first + count; i++) {
+        float *q = reinterpret_cast<float *>(&nodes[i * 8]);
+        for (int k = 0; k < 4; k++) {
+            int ref = __builtin_bit_cast(int, q[24 + k]);
+            if (ref >= 0) {
+                ref += node_base;
+            } else {
+                const int code = ~ref;
+                ref = ~((leaf_slot(code >> 1) << 1) | (code & 1));
+            }
+            q[24 + k] = __builtin_bit_cast(float, ref);
+        }
+    }
+}
+
+// A wide node with one child (a tree over a single item still needs a root to start from).
+inline void single_child_node(std::vector<f4> &nodes, const Box3 &b, int ref) {
+    nodes.resize(nodes.size() + 8, f4{0.0f, 0.0f, 0.0f, 0.0f});
+    float *q = reinterpret_cast<float *>(&nodes[nodes.size() - 8]);
+    float c[3], h[3];
+    center_half(b, c, h);
+    for (int k = 0; k < 4; k++)
+        for (int a = 0; a < 3; a++) {
+            q[6 * k + a] = k == 0 ? c[a] : 0.0f;
+            q[6 * k + 3 + a] = k == 0 ? h[a] : -1e30f;
+        }
+    for (int k = 0; k < 4; k++) q[24 + k] = __builtin_bit_cast(float, ref);
+    q[28] = __builtin_bit_cast(float, 1);
+}
 
 // flags: RT_SCENE_FORCE_* (rt_amd.h).  The descriptor must already be validated.
 // An external builder (the device-side one) gets the padded world-space boxes and the
@@ -698,6 +735,8 @@ inline int flatten_scene(const rt_scene_desc *d, uint32_t flags, HostScene &out,
     bool linear = n <= kLinearMaxPrims;
     if (flags & RT_SCENE_FORCE_BVH) linear = n < 2;
     if (flags & RT_SCENE_FORCE_LINEAR) linear = true;
+    const bool two_level = d->n_instances > 0;
+    if (two_level) linear = false; // a sub-scene is entered through a leaf of a tree
 
     std::vector<HostOp> ops(d->n_xform_ops);
     for (int i = 0; i < d->n_xform_ops; i++) ops[i] = make_op(d->xform_ops[i]);
@@ -780,7 +819,138 @@ inline int flatten_scene(const rt_scene_desc *d, uint32_t flags, HostScene &out,
     std::vector<i4> meta;
     std::vector<f4> &nodes = out.nodes;
     meta.resize(n);
-    if (linear) {
+    if (two_level) {
+        // ---- two-level tree: one tree per distinct sub-scene (in its own space), one over the loose
+        // primitives and the instances.  Slots: the loose primitives in the top tree's leaf order,
+        // then every sub-scene's in its own tree's leaf order; an instance is the leaf "slot"
+        // n + k of the top tree, and slot n + n_instances is the mark that ends a visit to one.
+        out.any_chain = true;
+        std::vector<std::pair<int, int>> t_range; // distinct sub-scenes
+        std::vector<int> inst_template(d->n_instances);
+        for (int k = 0; k < d->n_instances; k++) {
+            const std::pair<int, int> r{d->instances[k].first_prim, d->instances[k].n_prims};
+            size_t t = 0;
+            while (t < t_range.size() && t_range[t] != r) t++;
+            if (t == t_range.size()) t_range.push_back(r);
+            inst_template[k] = (int)t;
+        }
+        std::vector<char> in_template(n, 0);
+        for (const auto &r : t_range)
+            for (int i = r.first; i < r.first + r.second; i++) in_template[i] = 1;
+        struct Sub {
+            Wide wide;
+            std::vector<int> leaf_order; // local slot -> primitive
+            Box3 box;
+            int root_ref = 0, node_base = 0, slot_base = 0;
+        };
+        std::vector<Sub> subs(t_range.size());
+        int max_sub_levels = 0;
+        for (size_t t = 0; t < t_range.size(); t++) {
+            const int first = t_range[t].first, cnt = t_range[t].second;
+            std::vector<Box3> sb(boxes.begin() + first, boxes.begin() + first + cnt);
+            std::vector<int> st(types.begin() + first, types.begin() + first + cnt);
+            Sub &sub = subs[t];
+            sub.box.reset();
+            for (const Box3 &b : sb) sub.box.add(b);
+            if (cnt == 1) {
+                sub.leaf_order = {first};
+            } else {
+                BvhBuilder builder(sb, st);
+                BvhOut bo = builder.run();
+                sub.wide = collapse_to_wide(bo.nodes);
+                for (int local : bo.leaf_order) sub.leaf_order.push_back(first + local);
+                max_sub_levels = std::max(max_sub_levels, sub.wide.levels);
+            }
+        }
+        // items of the top tree: the loose primitives, then the instances
+        std::vector<Box3> ib;
+        std::vector<int> it, item_prim;
+        for (int i = 0; i < n; i++)
+            if (!in_template[i]) {
+                ib.push_back(boxes[i]);
+                it.push_back(types[i]);
+                item_prim.push_back(i);
+            }
+        const int n_loose = (int)item_prim.size();
+        for (int k = 0; k < d->n_instances; k++) {
+            const Sub &sub = subs[inst_template[k]];
+            Box3 b;
+            b.reset();
+            const int c = d->instances[k].xform;
+            const int first = c >= 0 ? d->chains[c].first_op : 0, last = c >= 0 ? first + d->chains[c].n_ops : 0;
+            for (int corner = 0; corner < 8; corner++) {
+                f3 q = mk((corner & 1) ? sub.box.hi[0] : sub.box.lo[0], (corner & 2) ? sub.box.hi[1] : sub.box.lo[1],
+                          (corner & 4) ? sub.box.hi[2] : sub.box.lo[2]);
+                for (int o = first; o < last; o++) q = op_point(ops[o], q);
+                b.add(q);
+            }
+            pad_box(b);
+            ib.push_back(b);
+            it.push_back(RT_PRIM_SPHERE);
+        }
+        const int n_items = (int)ib.size();
+        std::vector<int> top_order; // top slot -> item
+        Wide top;
+        if (n_items == 1) {
+            top_order = {0};
+            Box3 b = ib[0];
+            single_child_node(top.nodes, b, ~(it[0] == RT_PRIM_QUAD ? 1 : 0));
+            top.n_nodes = 1;
+            top.levels = 1;
+        } else {
+            BvhBuilder builder(ib, it);
+            BvhOut bo = builder.run();
+            top = collapse_to_wide(bo.nodes);
+            top_order = bo.leaf_order;
+        }
+        // final slots
+        std::vector<int> item_slot(n_items, -1), slot_prim;
+        for (int item : top_order)
+            if (item < n_loose) {
+                item_slot[item] = (int)slot_prim.size();
+                slot_prim.push_back(item_prim[item]);
+            }
+        for (int k = 0; k < d->n_instances; k++) item_slot[n_loose + k] = n + k;
+        int node_total = top.n_nodes;
+        for (Sub &sub : subs) {
+            sub.slot_base = (int)slot_prim.size();
+            slot_prim.insert(slot_prim.end(), sub.leaf_order.begin(), sub.leaf_order.end());
+            sub.node_base = node_total;
+            node_total += sub.wide.n_nodes;
+        }
+        nodes = std::move(top.nodes);
+        relocate_wide(nodes, 0, (size_t)top.n_nodes, 0, [&](int s0) { return item_slot[top_order[s0]]; });
+        for (size_t t = 0; t < subs.size(); t++) {
+            Sub &sub = subs[t];
+            const int cnt = t_range[t].second;
+            if (cnt == 1) {
+                sub.root_ref = ~(sub.slot_base * 2 + (types[t_range[t].first] == RT_PRIM_QUAD ? 1 : 0));
+                continue;
+            }
+            const size_t at = nodes.size() / 8;
+            nodes.insert(nodes.end(), sub.wide.nodes.begin(), sub.wide.nodes.end());
+            relocate_wide(nodes, at, (size_t)sub.wide.n_nodes, sub.node_base, [&](int s0) { return sub.slot_base + s0; });
+            sub.root_ref = sub.node_base;
+        }
+        nodes_to_plane_layout(nodes);
+        slots.resize((size_t)n * slot_f4);
+        for (int sl = 0; sl < n; sl++) {
+            const int pi = slot_prim[sl];
+            memcpy(&slots[(size_t)sl * slot_f4], &geom[(size_t)pi * slot_f4], sizeof(f4) * slot_f4);
+            meta[sl] = i4{types[pi], d->prims[pi].material, d->prims[pi].xform, pi};
+        }
+        // ids that order all primitives of the world: a loose one keeps its index, instance k's
+        // follow behind those of the instances before it
+        int next_id = n;
+        out.inst.resize(d->n_instances);
+        for (int k = 0; k < d->n_instances; k++) {
+            out.inst[k] = i4{subs[inst_template[k]].root_ref, d->instances[k].xform, next_id - d->instances[k].first_prim, 0};
+            next_id += d->instances[k].n_prims;
+        }
+        out.n_nodes = node_total;
+        out.bvh_depth = top.levels + max_sub_levels + 1; // (+1: the mark on the stack while inside an instance)
+        out.n_top = 0;
+    } else if (linear) {
         slots = geom;
         for (int i = 0; i < n; i++) meta[i] = i4{types[i], d->prims[i].material, d->prims[i].xform, i};
     } else {

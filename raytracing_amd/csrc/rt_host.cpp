@@ -154,7 +154,8 @@ int validate(const rt_scene_desc *d) {
     } arrays[] = {{"prims", d->n_prims, d->prims},           {"groups", d->n_groups, d->groups},
                   {"materials", d->n_materials, d->materials}, {"textures", d->n_textures, d->textures},
                   {"perlins", d->n_perlins, d->perlins},       {"images", d->n_images, d->images},
-                  {"xform_ops", d->n_xform_ops, d->xform_ops}, {"chains", d->n_chains, d->chains}};
+                  {"xform_ops", d->n_xform_ops, d->xform_ops}, {"chains", d->n_chains, d->chains},
+                  {"instances", d->n_instances, d->instances}};
     for (const auto &a : arrays) {
         if (a.n < 0) return fail(RT_ERR_ARG, "negative count of %s", a.name);
         if (a.n > 0 && !a.p) return fail(RT_ERR_ARG, "%s: %lld entries but a null array", a.name, a.n);
@@ -210,6 +211,21 @@ int validate(const rt_scene_desc *d) {
         if (c.first_op < 0 || c.n_ops < 0 || (long long)c.first_op + c.n_ops > d->n_xform_ops)
             return fail(RT_ERR_ARG, "chain %d: ops out of range", i);
     }
+    // instances: ranges inside the primitives, equal or disjoint; chains in range
+    if (d->n_instances > 0) {
+        std::vector<std::pair<int, int>> ranges;
+        for (int i = 0; i < d->n_instances; i++) {
+            const rt_instance &in = d->instances[i];
+            if (in.first_prim < 0 || in.n_prims < 1 || (long long)in.first_prim + in.n_prims > d->n_prims)
+                return fail(RT_ERR_ARG, "instance %d: primitive range out of bounds", i);
+            if (in.xform < -1 || in.xform >= d->n_chains) return fail(RT_ERR_ARG, "instance %d: chain out of range", i);
+            ranges.push_back({in.first_prim, in.n_prims});
+        }
+        std::sort(ranges.begin(), ranges.end());
+        for (size_t i = 1; i < ranges.size(); i++)
+            if (ranges[i] != ranges[i - 1] && ranges[i].first < ranges[i - 1].first + ranges[i - 1].second)
+                return fail(RT_ERR_ARG, "instances: two different primitive ranges overlap");
+    }
     return RT_OK;
 }
 
@@ -246,7 +262,8 @@ LaunchGeom choose_geom(rt_scene *s, uint32_t flags) {
     const int block = std::max(64, std::min(1024, env_int("RT_AMD_BLOCK", 1024) / 64 * 64));
     const int threads_per_cu = rtl::mega_waves_per_simd() * 256;
     const int bpc_target = std::max(1, env_int("RT_AMD_BLOCKS_PER_CU", threads_per_cu / block));
-    const bool short_ok = dv.n_nodes < 32768 && dv.n_slots < 16384; // 16-bit stack entries
+    // 16-bit stack entries (instances and the mark that ends a visit to one are leaf "slots" too)
+    const bool short_ok = dv.n_nodes < 32768 && dv.n_slots + dv.n_inst + 1 < 16384;
     lg.block = block;
     lg.lds_scene = false;
     lg.lds_records = 0;
@@ -296,7 +313,7 @@ LaunchGeom choose_geom(rt_scene *s, uint32_t flags) {
         // deep tree's stack, which few rays ever reach, spills to global memory), the rings and
         // the most visited nodes of the tree.
         int bits = 1;
-        while ((1ll << bits) < std::max<long long>(dv.n_nodes, 2ll * dv.n_slots)) bits++;
+        while ((1ll << bits) < std::max<long long>(dv.n_nodes, 2ll * (dv.n_slots + dv.n_inst + 1))) bits++;
         dv.ref_bits = std::max(16, std::min(32, bits + 1));
         lg.stack_lds_entries = bvh ? std::max(4, std::min(cap, env_int("RT_AMD_LDS_STACK", 24))) : 0;
         size_t stack = (size_t)lg.stack_lds_entries * RT_MEGA_MAX_THREADS * sizeof(int);
@@ -466,6 +483,7 @@ static int impl_rt_scene_create(const rt_scene_desc *d, int device, uint32_t fla
     if (rc == RT_OK) rc = upload(s, xf_packed, &dv.xf);
     if (rc == RT_OK) rc = upload(s, chain_first, &dv.chain_first);
     if (rc == RT_OK) rc = upload(s, hs.scan, &dv.scan);
+    if (rc == RT_OK) rc = upload(s, hs.inst, &dv.inst);
     if (rc == RT_OK) rc = upload(s, texs, &dv.textures);
     if (rc == RT_OK) rc = upload(s, hs.perlins, &dv.perlins);
     if (rc == RT_OK) rc = upload(s, imgs, &dv.images);
@@ -486,6 +504,7 @@ static int impl_rt_scene_create(const rt_scene_desc *d, int device, uint32_t fla
     s->d_words = const_cast<unsigned long long *>(dw);
     s->d_counters = const_cast<rtc::Counters *>(dc);
     dv.n_slots = n;
+    dv.n_inst = (int)hs.inst.size();
     dv.n_nodes = hs.n_nodes;
     dv.n_top = 0; // chosen with the launch geometry
     s->tree_top = hs.n_top;
@@ -504,6 +523,7 @@ static int impl_rt_scene_create(const rt_scene_desc *d, int device, uint32_t fla
     hipError_t e = rtl::static_scratch_setup(device); // this GPU's copy of the block rt_render_device_static uses
     if (e == hipSuccess) e = rtl::set_mega_lds_limit(kMaxLdsBytes);
     if (e == hipSuccess) e = rtl::set_mega_lds_limit_lean(kMaxLdsBytes);
+    if (e == hipSuccess) e = rtl::set_mega_lds_limit_inst(kMaxLdsBytes);
     if (e == hipSuccess) e = rtl::set_wavefront_lds_limit(kMaxLdsBytes);
     if (e != hipSuccess) {
         rt_scene_destroy(s);
@@ -684,6 +704,8 @@ static int impl_rt_render_device(rt_scene *s, const rt_camera_desc *cam, const r
     const bool wavefront = opts->mode == RT_MODE_WAVEFRONT;
     if (wavefront && (opts->flags & RT_RENDER_COUNTERS))
         return fail(RT_ERR_UNSUPPORTED, "the wavefront variant has no instrumented build");
+    if (wavefront && s->dev.n_inst > 0) // (its hit records carry no instance)
+        return fail(RT_ERR_UNSUPPORTED, "the wavefront variant does not render scenes with instances");
     rtc::DevCamera dc;
     int n_pixels = 0;
     int rc = check_render_args(s, cam, opts, dc, n_pixels);
@@ -863,7 +885,9 @@ static int impl_rt_render_device(rt_scene *s, const rt_camera_desc *cam, const r
         }
         if (stats) RT_HIP(hipEventRecord(ev.a, stream));
         if (!wavefront) {
-            if (s->lean)
+            if (dev.n_inst > 0)
+                RT_HIP(rtl::launch_mega_inst(dev, dc, rp, lg, ms));
+            else if (s->lean)
                 RT_HIP(rtl::launch_mega_lean(dev, dc, rp, lg, ms));
             else
                 RT_HIP(rtl::launch_mega(dev, dc, rp, lg, ms));
@@ -977,7 +1001,9 @@ static int impl_rt_render_device_static(rt_scene *s, const rt_camera_desc *cam, 
         rp.next_chunk = reinterpret_cast<unsigned *>(words);
         // the block keeps the last call's contents: the counters must start at zero
         RT_HIP(hipMemsetAsync(words, 0, 2 * sizeof(unsigned long long), stream));
-        if (s->lean)
+        if (dev.n_inst > 0)
+            RT_HIP(rtl::launch_mega_inst(dev, dc, rp, lg, stream));
+        else if (s->lean)
             RT_HIP(rtl::launch_mega_lean(dev, dc, rp, lg, stream));
         else
             RT_HIP(rtl::launch_mega(dev, dc, rp, lg, stream));
@@ -1017,7 +1043,10 @@ int rt_trace_batch_device(rt_scene *s, const rt_ray *d_rays, int64_t n, float tm
     if (rc != RT_OK) return rc;
     rtc::DevScene dev = s->dev;
     dev.ref_bits = 32; // whole keys on 32-bit stacks would do; the parity kernel keeps plain references
-    RT_HIP(rtl::launch_trace(dev, d_rays, n, tmin, tmax, d_hits, (hipStream_t)stream));
+    if (dev.n_inst > 0)
+        RT_HIP(rtl::launch_trace_inst(dev, d_rays, n, tmin, tmax, d_hits, (hipStream_t)stream));
+    else
+        RT_HIP(rtl::launch_trace(dev, d_rays, n, tmin, tmax, d_hits, (hipStream_t)stream));
     return RT_OK;
 }
 
@@ -1045,7 +1074,10 @@ int rt_trace_batch_sched_device(rt_scene *s, const rt_ray *d_rays, int64_t n, fl
     dev.lds_records = lg.lds_records;
     dev.lds_perlins = lg.lds_perlins;
     RT_HIP(hipMemsetAsync(s->d_words + 6, 0, sizeof(unsigned long long), stream));
-    RT_HIP(rtl::launch_trace_sched(dev, rp, lg, d_rays, n, tmin, tmax, d_hits, stream));
+    if (dev.n_inst > 0)
+        RT_HIP(rtl::launch_trace_sched_inst(dev, rp, lg, d_rays, n, tmin, tmax, d_hits, stream));
+    else
+        RT_HIP(rtl::launch_trace_sched(dev, rp, lg, d_rays, n, tmin, tmax, d_hits, stream));
     if (!s->ev_free[0]) RT_HIP(hipEventCreateWithFlags(&s->ev_free[0], hipEventDisableTiming));
     RT_HIP(hipEventRecord(s->ev_free[0], stream));
     s->ev_free_valid[0] = true;

@@ -25,12 +25,18 @@
 
 using namespace rtc;
 
-// This file is compiled twice: as is, and with -DRT_LEAN (render kernels only, without the
-// quad / noise / image branches; launchers suffixed _lean).
-#ifdef RT_LEAN
+// This file is compiled three times: as is; with -DRT_LEAN (render kernels only, without the
+// quad / noise / image / wrapper branches; launchers suffixed _lean); and with -DRT_INST (the
+// render and batch kernels with the two-level traversal of scenes that have instances;
+// launchers suffixed _inst).  Only the first build has the kernels that are no traversal
+// (reduce_stage, accum_add, tonemap_u8).
+#if defined(RT_LEAN)
 #define RT_LAUNCH_NAME(x) x##_lean
+#elif defined(RT_INST)
+#define RT_LAUNCH_NAME(x) x##_inst
 #else
 #define RT_LAUNCH_NAME(x) x
+#define RT_BASE_BUILD 1
 #endif
 
 
@@ -263,6 +269,7 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
             TraceHit h;
             h.t = tv.best_t;
             h.slot = tv.best_slot;
+            if (RT_FEAT_INSTANCE) h.inst = tv.best_inst;
             bool cont = path_after_trace<COUNT>(sc, vw, cam, ps, h, cn);
             if (cont) {
                 n_rays++;
@@ -466,7 +473,7 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
 #undef RT_TICK
 #undef RT_TOCK
 
-#ifndef RT_LEAN
+#ifdef RT_BASE_BUILD
 // accum[pixel] += sum over the launch's samples, in sample order; ray counts are
 // summed per workgroup and added to *ray_count.
 __global__ void __launch_bounds__(256) reduce_stage(const f4 *stage, int n_pixels, int sample_count,
@@ -521,6 +528,8 @@ __global__ void __launch_bounds__(256) tonemap_u8(const float *accum, long long 
     rgb8[i] = (uint8_t) int(256 * g);
 }
 
+#endif // RT_BASE_BUILD
+#ifndef RT_LEAN
 // hit_record of the closest hit (hittable.h:10-26) plus the primitive id.
 __device__ __forceinline__ rt_hit make_hit_record(const DevScene &sc, const SceneView &vw, const Ray &r, TraceHit h) {
     rt_hit out;
@@ -617,6 +626,7 @@ trace_sched(DevScene sc, RenderParams rp, const rt_ray *rays, long long n_rays, 
             TraceHit h;
             h.t = tv.best_t;
             h.slot = tv.best_slot;
+            if (RT_FEAT_INSTANCE) h.inst = tv.best_inst;
             hits[mine] = make_hit_record(sc, vw, ray, h);
             state = ST_IDLE;
         }
@@ -719,7 +729,7 @@ hipError_t RT_LAUNCH_NAME(launch_mega)(const DevScene &sc, const DevCamera &cam,
                         : launch_mega_bvh_tc<false, false>(sc, cam, rp, lg, stream);
 }
 
-#ifndef RT_LEAN
+#ifdef RT_BASE_BUILD
 int mega_waves_per_simd() { return RT_MEGA_WAVES_PER_SIMD; }
 
 // Workgroups of the decoupled render kernel the runtime will keep resident per CU.
@@ -729,7 +739,7 @@ int mega_blocks_per_cu(int block, int lds_bytes, bool lds_scene) {
                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_mega_bvh<false, false, false>, block, lds_bytes);
     return e == hipSuccess ? n : -1;
 }
-#endif // !RT_LEAN
+#endif // RT_BASE_BUILD
 
 hipError_t RT_LAUNCH_NAME(set_mega_lds_limit)(int bytes) {
     hipError_t e = hipSuccess;
@@ -781,7 +791,7 @@ hipError_t RT_LAUNCH_NAME(set_mega_lds_limit)(int bytes) {
     return e;
 }
 
-#ifndef RT_LEAN
+#ifdef RT_BASE_BUILD
 hipError_t launch_reduce(const f4 *stage, int n_pixels, int sample_count, float *accum,
                          unsigned long long *ray_count, unsigned *strip_cost, hipStream_t stream) {
     int grid = (n_pixels + 255) / 256;
@@ -804,7 +814,9 @@ hipError_t launch_tonemap(const float *accum, long long n_components, float scal
     return hipGetLastError();
 }
 
-hipError_t launch_trace(const DevScene &sc, const rt_ray *rays, long long n, float tmin, float tmax,
+#endif // RT_BASE_BUILD
+#ifndef RT_LEAN
+hipError_t RT_LAUNCH_NAME(launch_trace)(const DevScene &sc, const rt_ray *rays, long long n, float tmin, float tmax,
                         rt_hit *hits, hipStream_t stream) {
     long long want = (n + RT_TRACE_THREADS - 1) / RT_TRACE_THREADS;
     int grid = (int)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
@@ -820,7 +832,7 @@ hipError_t launch_trace(const DevScene &sc, const rt_ray *rays, long long n, flo
 
 // rp: stack_lds_entries, stack_spill, min_ready / leaf_min / blocked_min and next_chunk (an
 // 8-byte counter, zeroed) are used; lg is the scene's render geometry.
-hipError_t launch_trace_sched(const DevScene &sc, const RenderParams &rp, const LaunchGeom &lg, const rt_ray *rays,
+hipError_t RT_LAUNCH_NAME(launch_trace_sched)(const DevScene &sc, const RenderParams &rp, const LaunchGeom &lg, const rt_ray *rays,
                               long long n, float tmin, float tmax, rt_hit *hits, hipStream_t stream) {
     if (lg.lds_scene)
         hipLaunchKernelGGL((trace_sched<true>), dim3(lg.grid), dim3(lg.block), lg.lds_bytes, stream, sc, rp, rays, n,

@@ -103,6 +103,10 @@ hipError_t set_mega_lds_limit(int bytes);
 hipError_t launch_mega_lean(const rtc::DevScene &sc, const rtc::DevCamera &cam, const RenderParams &rp,
                             const LaunchGeom &lg, hipStream_t stream);
 hipError_t set_mega_lds_limit_lean(int bytes);
+// ... and with the two-level traversal of scenes that have instances (DevScene::n_inst > 0)
+hipError_t launch_mega_inst(const rtc::DevScene &sc, const rtc::DevCamera &cam, const RenderParams &rp,
+                            const LaunchGeom &lg, hipStream_t stream);
+hipError_t set_mega_lds_limit_inst(int bytes);
 int mega_waves_per_simd(); // register budget the render kernels were compiled for
 int mega_blocks_per_cu(int block, int lds_bytes, bool lds_scene);
 hipError_t launch_reduce(const rtc::f4 *stage, int n_pixels, int sample_count, float *accum,
@@ -122,4 +126,9 @@ hipError_t launch_trace(const rtc::DevScene &sc, const rt_ray *rays, long long n
                         rt_hit *hits, hipStream_t stream);
 hipError_t launch_trace_sched(const rtc::DevScene &sc, const RenderParams &rp, const LaunchGeom &lg, const rt_ray *rays,
                               long long n, float tmin, float tmax, rt_hit *hits, hipStream_t stream);
+hipError_t launch_trace_inst(const rtc::DevScene &sc, const rt_ray *rays, long long n, float tmin, float tmax,
+                             rt_hit *hits, hipStream_t stream);
+hipError_t launch_trace_sched_inst(const rtc::DevScene &sc, const RenderParams &rp, const LaunchGeom &lg,
+                                   const rt_ray *rays, long long n, float tmin, float tmax, rt_hit *hits,
+                                   hipStream_t stream);
 } // namespace rtl

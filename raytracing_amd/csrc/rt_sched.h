@@ -56,6 +56,9 @@ __device__ __forceinline__ void wave_traverse(int &state, Trav &tv, Parked &pend
                                               int leaf_min, int blocked_min, bool idle_counts, Cnt<COUNT> &cn,
                                               SchedStats &ss) {
     long long c_mark = 0;
+    // two-level scenes: leaves that enter or leave an instance are dealt with among the leaf tests,
+    // and a lane does not walk on past one (rt_core.h trav_barrier)
+    const bool inst_scene = RT_FEAT_INSTANCE && sc.n_inst > 0;
     for (;;) {
         unsigned long long tmask = __ballot(state == ST_TRAV);
         if (tmask == 0ull) break;
@@ -78,7 +81,8 @@ __device__ __forceinline__ void wave_traverse(int &state, Trav &tv, Parked &pend
             if (trav && tv.ref >= 0)
                 trav_inner<COUNT, ST, !LDS_SCENE, SPILL, LDS_SCENE ? RT_NODE_LDS_F4 : RT_NODE_F4>(tv, vw.nodes, tmin, st, sc.ref_bits, cn, vw.top,
                                                                                                      vw.n_top);
-            if (trav && tv.ref < 0 && tv.ref != RT_TRAV_DONE && !pend.full()) {
+            if (trav && tv.ref < 0 && tv.ref != RT_TRAV_DONE && !pend.full() &&
+                !(inst_scene && trav_is_barrier(sc, tv.ref))) {
                 pend.put(tv.ref);
                 trav_pop<ST, SPILL>(tv, st, sc.ref_bits);
             }
@@ -90,7 +94,8 @@ __device__ __forceinline__ void wave_traverse(int &state, Trav &tv, Parked &pend
         }
         const bool blocked = trav && tv.ref < 0 && tv.ref != RT_TRAV_DONE; // another leaf, no slot left
         const bool has_pend = trav && pend.a != 0;
-        unsigned long long pmask = __ballot(has_pend);
+        const bool at_barrier = inst_scene && trav && trav_is_barrier(sc, tv.ref);
+        unsigned long long pmask = __ballot(has_pend || at_barrier);
         if (pmask != 0ull) {
             unsigned long long imask = __ballot(trav && tv.ref >= 0);
             unsigned long long bmask = __ballot(blocked);
@@ -99,12 +104,12 @@ __device__ __forceinline__ void wave_traverse(int &state, Trav &tv, Parked &pend
                     ss.l_iters++;
                     ss.l_lanes += __popcll(pmask);
                 }
-                if (has_pend) {
-                    trav_test_leaf<COUNT>(tv, pend.take(), sc, vw, ray, tmin, cn);
-                    if (blocked) {
-                        pend.put(tv.ref);
-                        trav_pop<ST, SPILL>(tv, st, sc.ref_bits);
-                    }
+                if (has_pend) trav_test_leaf<COUNT>(tv, pend.take(), sc, vw, ray, tmin, cn);
+                if (at_barrier) { // (after the parked leaf, which belongs to the space the lane is still in)
+                    trav_barrier<ST, SPILL>(tv, sc, ray, st);
+                } else if (has_pend && blocked) {
+                    pend.put(tv.ref);
+                    trav_pop<ST, SPILL>(tv, st, sc.ref_bits);
                 }
             }
         }

@@ -50,6 +50,8 @@ void *sim_scene_create(const rt_scene_desc *d, uint32_t flags) {
     dv.images = s->imgs.data();
     dv.texels = s->texels.data();
     dv.n_slots = s->hs.n_prims;
+    dv.inst = s->hs.inst.data();
+    dv.n_inst = (int)s->hs.inst.size();
     dv.n_nodes = s->hs.n_nodes;
     dv.slot_f4 = s->hs.slot_f4;
     dv.traversal = s->hs.linear ? TRAV_LINEAR : TRAV_BVH;
@@ -58,7 +60,7 @@ void *sim_scene_create(const rt_scene_desc *d, uint32_t flags) {
     dv.stack_cap = RT_STACK_CAP(s->hs.bvh_depth);
     {   // as the library chooses it for a scene that stays in global memory
         int bits = 1;
-        while ((1ll << bits) < std::max<long long>(dv.n_nodes, 2ll * dv.n_slots)) bits++;
+        while ((1ll << bits) < std::max<long long>(dv.n_nodes, 2ll * (dv.n_slots + dv.n_inst + 1))) bits++;
         dv.ref_bits = std::max(16, std::min(32, bits + 1));
     }
     return s;
@@ -92,7 +94,7 @@ struct SimStacks {
 };
 template <bool COUNT> TraceHit sim_trace_bvh(DevScene sc, const SceneView &vw, const Ray &r, float tmin, float tmax,
                                              SimStacks &k, Cnt<COUNT> &cn) {
-    if (g_stack_mode == 1 && sc.n_nodes < 32768 && sc.n_slots < 16384) {
+    if (g_stack_mode == 1 && sc.n_nodes < 32768 && sc.n_slots + sc.n_inst + 1 < 16384) {
         sc.ref_bits = 16;
         return trace_bvh<COUNT, TravStack<short>, false>(sc, vw, r, tmin, tmax, k.st16, cn);
     }

@@ -454,3 +454,156 @@ def test_host_logic_under_address_and_ub_sanitizers(tmp_path):
     assert run.returncode == 0, out[-3000:]
     assert "runtime error" not in out and "AddressSanitizer" not in out and "LeakSanitizer" not in out, out[-3000:]
     assert out.count("flags") >= 3 * len(scenes) - 1
+
+
+def two_level_scene(seed=21):
+    """A world of loose primitives plus sub-scenes placed several times (rt_instance): a cluster of
+    spheres and quads (some inside wrappers of their own) under 14 different wrapper chains and as it
+    is, and a lone sphere under three.  Returns the scene and the same scene with every instance
+    written out as primitives (loose primitives first, then instance by instance), with, per
+    written-out primitive, the primitive of the instanced scene it stands for."""
+    rng = np.random.default_rng(seed)
+    ops, chains = [], []
+
+    def chain(*items):
+        first = len(ops)
+        ops.extend(items)
+        chains.append((first, len(items)))
+        return len(chains) - 1
+
+    prims = []
+
+    def sphere(c, r, xform=-1, mat=0):
+        p = np.zeros((), abi.PRIM_DT)
+        p["type"], p["material"], p["xform"] = abi.RT_PRIM_SPHERE, mat, xform
+        p["a"], p["c"] = c, (r, 0, 0)
+        prims.append(p)
+
+    def quad(q, u, v, xform=-1, mat=0):
+        p = np.zeros((), abi.PRIM_DT)
+        p["type"], p["material"], p["xform"] = abi.RT_PRIM_QUAD, mat, xform
+        p["a"], p["b"], p["c"] = q, u, v
+        prims.append(p)
+
+    sphere((0, -1000, 0), 1000.0, mat=1)                      # loose: ground and a few spheres
+    for _ in range(9):
+        sphere(rng.uniform(-30, 30, 3) * (1, 0, 1) + (0, 0.5, 0), 0.5, mat=int(rng.integers(0, 4)))
+    a_first = len(prims)                                      # sub-scene A: 40 spheres, 8 quads
+    for i in range(40):
+        xf = chain((abi.RT_XF_SCALE, (1.0, 0.6, 1.3)), (abi.RT_XF_ROTATE_Y, (25.0, 0, 0))) if i % 10 == 3 else -1
+        sphere(rng.uniform(-2, 2, 3), float(rng.uniform(0.15, 0.5)), xform=xf, mat=int(rng.integers(0, 4)))
+    for i in range(8):
+        xf = chain((abi.RT_XF_ROTATE_XYZ, (10.0, 20.0, 30.0)), (abi.RT_XF_TRANSLATE, (0.3, 0.0, -0.2))) if i % 4 == 1 else -1
+        quad(rng.uniform(-2, 2, 3), rng.uniform(-1, 1, 3), rng.uniform(-1, 1, 3), xform=xf, mat=int(rng.integers(0, 4)))
+    a_count = len(prims) - a_first
+    sphere((20, 3, 20), 1.0, mat=2)                           # a loose primitive between the sub-scenes
+    b_first = len(prims)                                      # sub-scene B: one sphere
+    sphere((0, 0, 0), 0.8, mat=3)
+    instances = [(a_first, a_count, -1, 0)]
+    for k in range(14):
+        items = []
+        if k % 3 == 0:
+            items.append((abi.RT_XF_SCALE, tuple(rng.uniform(0.5, 1.8, 3))))
+        if k % 2 == 0:
+            items.append((abi.RT_XF_ROTATE_XYZ, tuple(rng.uniform(-80, 80, 3))))
+        else:
+            items.append((abi.RT_XF_ROTATE_Y, (float(rng.uniform(-180, 180)), 0, 0)))
+        items.append((abi.RT_XF_TRANSLATE, tuple(rng.uniform(-25, 25, 3) * (1, 0.2, 1) + (0, 4, 0))))
+        instances.append((a_first, a_count, chain(*items), 0))
+    for k in range(3):
+        instances.append((b_first, 1, chain((abi.RT_XF_SCALE, (1.0 + k, 1.0, 1.0)),
+                                            (abi.RT_XF_TRANSLATE, (-10.0 + 10 * k, 8.0, -12.0))), 0))
+    mats = np.zeros(4, abi.MATERIAL_DT)
+    mats["type"] = (abi.RT_MAT_LAMBERTIAN, abi.RT_MAT_LAMBERTIAN, abi.RT_MAT_METAL, abi.RT_MAT_DIELECTRIC)
+    mats["texture"] = (0, 1, 0, 0)
+    mats["albedo"][2] = (0.8, 0.8, 0.9)
+    mats["param"] = (0, 0, 0.05, 1.5)
+    tex = np.zeros(2, abi.TEXTURE_DT)
+    tex["color"] = ((0.7, 0.3, 0.2), (0.5, 0.5, 0.5))
+    prims = np.array(prims, abi.PRIM_DT)
+    scene = abi.SceneArrays(prims=prims, materials=mats, textures=tex, xform_ops=np.array(ops, abi.XFORM_OP_DT),
+                            chains=np.array(chains, abi.CHAIN_DT), instances=np.array(instances, abi.INSTANCE_DT))
+    # written out: a primitive of an instance carries its own wrappers, then the instance's (outer)
+    in_sub = np.zeros(len(prims), bool)
+    for f, n, _, _ in instances:
+        in_sub[f:f + n] = True
+    flat, origin = [prims[i] for i in np.flatnonzero(~in_sub)], list(np.flatnonzero(~in_sub))
+    ops2, chains2 = list(ops), list(chains)
+    for f, n, xf, _ in instances:
+        for j in range(f, f + n):
+            p = prims[j].copy()
+            items = []
+            if p["xform"] >= 0:
+                c0, cn = chains[int(p["xform"])]
+                items += ops[c0:c0 + cn]
+            if xf >= 0:
+                c0, cn = chains[xf]
+                items += ops[c0:c0 + cn]
+            if items:
+                chains2.append((len(ops2), len(items)))
+                ops2.extend(items)
+                p["xform"] = len(chains2) - 1
+            else:
+                p["xform"] = -1
+            flat.append(p)
+            origin.append(j)
+    written_out = abi.SceneArrays(prims=np.array(flat, abi.PRIM_DT), materials=mats, textures=tex,
+                                  xform_ops=np.array(ops2, abi.XFORM_OP_DT), chains=np.array(chains2, abi.CHAIN_DT))
+    return scene, written_out, np.array(origin)
+
+
+def two_level_rays(n, seed=5):
+    rng = np.random.default_rng(seed)
+    rays = np.zeros(n, abi.RAY_DT)
+    o = rng.normal(size=(n, 3))
+    o *= rng.uniform(5, 60, size=(n, 1)) / np.linalg.norm(o, axis=1, keepdims=True)
+    o[:, 1] = np.abs(o[:, 1]) + 0.5
+    tgt = rng.uniform(-28, 28, (n, 3)) * (1, 0.25, 1) + (0, 3, 0)
+    rays["orig"], rays["dir"], rays["tm"] = o, (tgt - o) * rng.uniform(0.3, 2.0, (n, 1)), rng.uniform(0, 1, n)
+    return rays
+
+
+def check_two_level_hits(hits, ref, origin):
+    """hits of the instanced scene against the oracle's of the written-out one."""
+    m = ref["prim"] >= 0
+    assert np.array_equal(hits["prim"] >= 0, m)
+    assert np.array_equal(hits["prim"][m], origin[ref["prim"][m]]), "another primitive"
+    for f in ("t", "p", "normal", "front_face"):
+        assert np.array_equal(hits[f][m], ref[f][m]), f
+
+
+def test_kernel_logic_two_level_scene():
+    """rt_instance: the tree over instances and the trees of the sub-scenes, walked by the kernels' own
+    traversal code on the host (every stack variant), against the oracle's scan of the same scene with
+    every instance written out: the same primitive, t, p, normal and face, bit for bit."""
+    scene, written_out, origin = two_level_scene()
+    rays = two_level_rays(40_000)
+    ref, _ = O.OracleScene(written_out).trace(rays, 0.001, np.inf, O.TRACE_REFERENCE)
+    assert 0.3 < (ref["prim"] >= 0).mean() and len(np.unique(ref["prim"])) > 300
+    sim = S.SimScene(scene)
+    assert sim.n_nodes < 60  # 48 + 1 sub-scene primitives and 29 items at the top: not 48 x 15 primitives
+    for mode in (0, 1, 2):
+        S.set_stack_mode(mode)
+        try:
+            hits, _, _ = sim.trace(rays)
+        finally:
+            S.set_stack_mode(0)
+        check_two_level_hits(hits, ref, origin)
+
+
+def test_instance_descriptors_are_validated():
+    """Ranges outside the primitives, partially overlapping ranges and chains out of range are refused
+    before anything is built (no GPU needed: validation comes first)."""
+    scene, _, _ = two_level_scene()
+    L = binding.lib()
+    for edit in ("range", "overlap", "chain"):
+        bad = abi.SceneArrays(**{name: getattr(scene, name).copy() for name, _ in abi.SceneArrays.FIELDS})
+        if edit == "range":
+            bad.instances[0]["n_prims"] = len(bad.prims)
+        elif edit == "overlap":
+            bad.instances[1]["first_prim"] += 1
+        else:
+            bad.instances[2]["xform"] = len(bad.chains)
+        d = bad.desc()
+        out = C.c_void_p()
+        assert L.rt_scene_create(C.byref(d), 0, 0, C.byref(out)) == abi.RT_ERR_ARG, edit
