@@ -233,6 +233,47 @@ static void rotated_in_bvh() {
     shoot(world, View{kWide, 240, 10, kSky, 35.0f, point3(6.0f, 4.0f, 9.0f), point3(0.0f, 0.8f, 0.0f), 0.0f, 10.0f});
 }
 
+// One shrub (60 spheres and 4 quads under a bvh_node) handed to 120 instance wrappers
+// (hittable.h:51-344): the reference walks the one shrub through every wrapper; the drop-in records
+// it once and places it with rt_instance records, so the library keeps 65 primitives, not 7 681
+// (RTAMD_INSTANCES=0 writes every copy out, with the same image).  No counterpart in main.cpp.
+static void grove() {
+    uint64_t state = 0xC0FFEEull;
+    auto u01 = [&]() {
+        uint64_t z = (state += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        return float(z >> 40) * (1.0f / 16777216.0f);
+    };
+    hittable_list shrub;
+    auto leaf = make_shared<lambertian>(color(0.15f, 0.45f, 0.12f));
+    auto berry = make_shared<metal>(color(0.8f, 0.2f, 0.2f), 0.2f);
+    auto dew = make_shared<dielectric>(1.5f);
+    for (int i = 0; i < 60; i++) {
+        float x = 1.6f * (u01() - 0.5f), y = 0.2f + 1.4f * u01(), z = 1.6f * (u01() - 0.5f), r = 0.08f + 0.18f * u01();
+        shared_ptr<material> m = i % 7 == 0 ? berry : (i % 11 == 0 ? dew : (shared_ptr<material>)leaf);
+        shrub.add(make_shared<sphere>(point3(x, y, z), r, m));
+    }
+    auto bark = make_shared<lambertian>(color(0.35f, 0.25f, 0.15f));
+    shrub.add(make_shared<quad>(point3(-0.05f, 0.0f, -0.05f), vec3(0.1f, 0.0f, 0.0f), vec3(0.0f, 0.9f, 0.0f), bark));
+    shrub.add(make_shared<quad>(point3(-0.05f, 0.0f, 0.05f), vec3(0.1f, 0.0f, 0.0f), vec3(0.0f, 0.9f, 0.0f), bark));
+    shrub.add(make_shared<quad>(point3(-0.05f, 0.0f, -0.05f), vec3(0.0f, 0.0f, 0.1f), vec3(0.0f, 0.9f, 0.0f), bark));
+    shrub.add(make_shared<quad>(point3(0.05f, 0.0f, -0.05f), vec3(0.0f, 0.0f, 0.1f), vec3(0.0f, 0.9f, 0.0f), bark));
+    shared_ptr<hittable> one = make_shared<bvh_node>(shrub);
+
+    hittable_list world;
+    world.add(make_shared<sphere>(point3(0.0f, -1000.0f, 0.0f), 1000.0f, make_shared<lambertian>(ground_checker())));
+    for (int a = -6; a < 6; a++)
+        for (int b = -5; b < 5; b++) {
+            float jx = u01(), jz = u01(), angle = 360.0f * u01(), size = 0.7f + 0.8f * u01();
+            shared_ptr<hittable> h = make_shared<rotate_y>(one, angle);
+            if ((a + b) & 1) h = make_shared<scaling>(h, vec3(size, size * 1.2f, size));
+            world.add(make_shared<translate>(h, vec3(3.0f * a + 1.5f * jx, 0.0f, 3.0f * b + 1.5f * jz)));
+        }
+    shoot(world, View{kWide, 640, 16, kSky, 35.0f, point3(4.0f, 9.0f, 26.0f), point3(0.0f, 1.0f, 0.0f), 0.0f, 10.0f});
+}
+
 // 10^6 cells on a grid, one sphere or quad per cell, plus the ground: splitmix64 keyed layout,
 // twelve draws per cell whether they are used or not.
 static void synth1m(int half) {
@@ -294,6 +335,7 @@ int main(int argc, char **argv) {
     else if (s == "simple_light") simple_light();
     else if (s == "cornell_box") cornell_box();
     else if (s == "rotated_in_bvh") rotated_in_bvh();
+    else if (s == "grove") grove();
     else if (s == "synth1m") synth1m(synth_half);
     else {
         fprintf(stderr, "unknown scene %s\n", argv[1]);

@@ -270,6 +270,62 @@ class Recorder {
     std::map<const void *, int> material_ids, texture_ids;
     std::map<std::string, int> chain_ids;
     int bvh_depth = 0; // > 0 while recording the leaves of a bvh_node
+    // Objects that several instance wrappers hold (hittable.h:51-344 keep a shared_ptr to what they
+    // move) are recorded once, as a sub-scene, and placed by rt_instance records: the library then
+    // keeps one copy and one tree of them.  A first, counting pass over the scene (`counting`) finds
+    // them: per object, how often a wrapper reached it and how many primitives it holds; the
+    // recording pass gets that table in `shared`.
+    bool counting = false;
+    std::map<const void *, std::pair<int, int>> seen;
+    const std::map<const void *, std::pair<int, int>> *shared = nullptr;
+    std::map<const void *, std::pair<int, int>> sub_scenes; // object -> {first_prim, n_prims}
+    std::vector<rt_instance> instances;
+    bool in_sub_scene = false;
+    static const int kMinInstancePrims = 8; // smaller objects are cheaper written out
+
+    // Called by a wrapper for the object it holds, with its own op already on open_wrappers.
+    template <class F> void child(const void *obj, F record_it) {
+        if (counting) {
+            std::pair<int, int> &c = seen[obj];
+            c.first++;
+            const size_t before = prims.size();
+            record_it();
+            c.second = (int)(prims.size() - before);
+            return;
+        }
+        const std::pair<int, int> *c = nullptr;
+        if (shared && !in_sub_scene) {
+            auto it = shared->find(obj);
+            if (it != shared->end() && it->second.first >= 2 && it->second.second >= kMinInstancePrims) c = &it->second;
+        }
+        if (!c) {
+            record_it();
+            return;
+        }
+        auto t = sub_scenes.find(obj);
+        if (t == sub_scenes.end()) { // first visit: its primitives, in its own space
+            std::vector<rt_xform_op> outer;
+            outer.swap(open_wrappers);
+            const int outer_depth = bvh_depth;
+            bvh_depth = 0;
+            bvh_closed = true;
+            in_sub_scene = true;
+            const int first = (int)prims.size();
+            record_it();
+            in_sub_scene = false;
+            bvh_depth = outer_depth;
+            bvh_closed = true;
+            open_wrappers.swap(outer);
+            t = sub_scenes.emplace(obj, std::make_pair(first, (int)prims.size() - first)).first;
+        }
+        rt_instance in = {t->second.first, t->second.second, current_chain(), 0};
+        instances.push_back(in);
+    }
+    bool any_shared() const {
+        for (const auto &kv : seen)
+            if (kv.second.first >= 2 && kv.second.second >= kMinInstancePrims) return true;
+        return false;
+    }
 
     int current_chain() {
         if (open_wrappers.empty()) return -1;
@@ -321,6 +377,8 @@ class Recorder {
         d.xform_ops = ops.data();
         d.n_chains = (int)chains.size();
         d.chains = chains.data();
+        d.n_instances = (int)instances.size();
+        d.instances = instances.data();
         return d;
     }
 
@@ -863,7 +921,7 @@ class translate : public hittable {
     void record(rtamd::Recorder &r) const override {
         rt_xform_op op = {RT_XF_TRANSLATE, {offset[0], offset[1], offset[2]}};
         r.open_wrappers.push_back(op);
-        object->record(r);
+        r.child(object.get(), [&] { object->record(r); });
         r.open_wrappers.pop_back();
     }
 
@@ -922,7 +980,7 @@ class rotate_y : public hittable {
     void record(rtamd::Recorder &r) const override {
         rt_xform_op op = {RT_XF_ROTATE_Y, {angle, 0.0f, 0.0f}};
         r.open_wrappers.push_back(op);
-        object->record(r);
+        r.child(object.get(), [&] { object->record(r); });
         r.open_wrappers.pop_back();
     }
 
@@ -961,7 +1019,7 @@ class rotate_xyz : public hittable {
     void record(rtamd::Recorder &r) const override {
         rt_xform_op op = {RT_XF_ROTATE_XYZ, {alpha, beta, gamma}};
         r.open_wrappers.push_back(op);
-        object->record(r);
+        r.child(object.get(), [&] { object->record(r); });
         r.open_wrappers.pop_back();
     }
 
@@ -987,7 +1045,7 @@ class scaling : public hittable {
     void record(rtamd::Recorder &r) const override {
         rt_xform_op op = {RT_XF_SCALE, {scale[0], scale[1], scale[2]}};
         r.open_wrappers.push_back(op);
-        object->record(r);
+        r.child(object.get(), [&] { object->record(r); });
         r.open_wrappers.pop_back();
     }
 
@@ -1260,7 +1318,15 @@ class camera {
     // library is printed and the process exits, since no image can be produced.
     void render(const hittable &world, const char *file_name) {
         auto t0 = std::chrono::steady_clock::now();
-        rtamd::Recorder rec;
+        // objects that several wrappers share become sub-scenes with instances (RTAMD_INSTANCES=0:
+        // everything written out, as before); a scene that shares nothing records exactly as it did
+        rtamd::Recorder counted, rec;
+        const char *inst_env = getenv("RTAMD_INSTANCES");
+        if (!inst_env || atoi(inst_env) != 0) {
+            counted.counting = true;
+            world.record(counted);
+            if (counted.any_shared()) rec.shared = &counted.seen;
+        }
         world.record(rec);
         rt_scene_desc sd = rec.desc();
         rt_camera_desc cd = descriptor();

@@ -159,6 +159,37 @@ def test_host_side_hit_matches_the_reference_records(scene, tmp_path):
         assert np.array_equal(hits[f][m], ref[f][m]), f
 
 
+def test_shared_objects_become_instances(tmp_path):
+    """An object handed to many instance wrappers (examples/scenes.cpp grove: one shrub under 120
+    rotate_y / scaling / translate chains) is recorded once and placed by rt_instance records;
+    RTAMD_INSTANCES=0 writes every copy out.  The kernels' traversal (compiled for the host) over the
+    instanced scene gives, ray for ray, what the oracle's scan of the written-out scene gives: the
+    same primitive of the shrub, t, p, normal and face, bit for bit."""
+    from tests import sim_lib as S
+    _ensure_built()
+    inst, flat = str(tmp_path / "grove.rtscene"), str(tmp_path / "grove_flat.rtscene")
+    subprocess.run([RT_SCENES, "grove", "--dump", inst], check=True, capture_output=True)
+    subprocess.run([RT_SCENES, "grove", "--dump", flat], check=True, capture_output=True,
+                   env=dict(os.environ, RTAMD_INSTANCES="0"))
+    a, b = abi.SceneArrays.load(inst), abi.SceneArrays.load(flat)
+    assert len(a.prims) == 65 and len(a.instances) == 120 and len(b.prims) == 1 + 120 * 64 and len(b.instances) == 0
+    assert (a.instances["first_prim"] == 1).all() and (a.instances["n_prims"] == 64).all()
+    cam, _ = abi.load_camera_file(inst + ".cam")
+    rng = np.random.default_rng(3)
+    n = 20_000
+    rays = np.zeros(n, abi.RAY_DT)
+    rays["orig"] = rng.uniform(-1, 1, (n, 3)) * (20, 4, 20) + (0, 6, 0)
+    rays["dir"] = rng.uniform(-18, 18, (n, 3)) * (1, 0.05, 1) + (0, 0.8, 0) - rays["orig"]
+    ref, _ = O.OracleScene(b).trace(rays, 0.001, np.inf, O.TRACE_REFERENCE)
+    hits, _, _ = S.SimScene(a).trace(rays)
+    m = ref["prim"] >= 0
+    assert m.mean() > 0.5 and (ref["prim"][m] > 0).mean() > 0.2  # the shrubs are hit, not only the ground
+    origin = np.where(ref["prim"] > 0, 1 + (ref["prim"] - 1) % 64, ref["prim"])
+    assert np.array_equal(hits["prim"], origin)
+    for f in ("t", "p", "normal", "front_face"):
+        assert np.array_equal(hits[f][m], ref[f][m]), f
+
+
 def test_host_side_materials_and_textures(tmp_path):
     """material::scatter / emitted and texture::value on the host (material.h:13-20, texture.h:13):
     tests/host_virtuals.cpp checks them against closed forms and against the oracle-independent
@@ -226,6 +257,24 @@ def test_scene_program_renders_png(tmp_path):
     acc, _ = sc.render(cam, 32, seed=0)
     assert np.array_equal(img, binding.tonemap_u8(acc, 1.0 / 32))
     sc.close()
+
+
+@pytest.mark.gpu
+def test_shared_objects_render_the_same_as_instances_and_written_out(tmp_path):
+    """The grove scene through camera::render of the drop-in, once with its shrub recorded as a
+    sub-scene with 120 instances (the default) and once with every copy written out
+    (RTAMD_INSTANCES=0): the same picture (a hit that rounding alone decides may fall either way
+    with the order boxes are visited in, which differs between the two trees: a handful of pixels)."""
+    from PIL import Image
+    imgs = []
+    for env in ({}, {"RTAMD_INSTANCES": "0"}):
+        png = str(tmp_path / f"grove{len(imgs)}.png")
+        r = subprocess.run([RT_SCENES, "grove", "--spp", "8", "--width", "400", "--out", png], check=True,
+                           capture_output=True, env=dict(os.environ, **env))
+        assert b"Render took" in r.stderr
+        imgs.append(np.asarray(Image.open(png).convert("RGB")).astype(int))
+    assert imgs[0].std() > 10
+    assert (imgs[0] != imgs[1]).any(axis=2).mean() < 1e-3
 
 
 @pytest.mark.gpu
