@@ -705,6 +705,8 @@ struct Trav {
     float dd; // |d|^2 of the world-space ray
     int cur_inst;  // the instance whose sub-scene is being walked (-1: the world's own tree)
     int best_inst; // the instance of the closest hit so far
+    f3 io, id;     // inside an instance: the ray in the sub-scene's space (taken there once, on entry)
+    float idd;     // ... and |d|^2 there
 };
 RT_HD void trav_begin(Trav &tv, const Ray &r, float tmax) {
     tv.br = make_box_ray(r);
@@ -912,12 +914,10 @@ RT_HD void trav_test_leaf(Trav &tv, int leaf_ref, const DevScene &sc, const Scen
     int id_off = 0, best_id_off = 0;
     if (RT_FEAT_INSTANCE && sc.n_inst > 0) { // inside an instance: its wrappers first (the outer ones)
         if (tv.cur_inst >= 0) {
-            const i4 in = sc.inst[tv.cur_inst];
-            id_off = in.z;
-            if (in.y >= 0) {
-                chain_ray_to_object(sc, in.y, o, d);
-                dd = len2(d);
-            }
+            id_off = sc.inst[tv.cur_inst].z;
+            o = tv.io;
+            d = tv.id;
+            dd = tv.idd;
         }
         if (tv.best_inst >= 0) best_id_off = sc.inst[tv.best_inst].z;
     }
@@ -982,6 +982,9 @@ RT_HD void trav_barrier(Trav &tv, const DevScene &sc, const Ray &world, const ST
         tv.cur_inst = k;
         Ray r = world;
         if (in.y >= 0) chain_ray_to_object(sc, in.y, r.o, r.d);
+        tv.io = r.o;
+        tv.id = r.d;
+        tv.idd = in.y >= 0 ? len2(r.d) : tv.dd;
         tv.br = make_box_ray(r);
         tv.ref = in.x;
     } else { // leave
