@@ -58,3 +58,25 @@ def test_instanced_scene_renders_like_the_written_out_one():
         a.render(cam, 8, seed=3, mode=abi.RT_MODE_WAVEFRONT)  # its hit records carry no instance
     a.close()
     b.close()
+
+
+def test_instanced_scene_through_the_other_entry_points():
+    """The same two-level scene through the entry point that allocates nothing and through the
+    multi-GPU replicas (device 0 listed twice): the image of the plain render (the replicas add
+    their halves of the samples, so theirs agrees up to the order of fp32 additions)."""
+    import torch
+    B = _binding()
+    scene, _, _ = two_level_scene()
+    cam = abi.CameraDesc(16 / 9, 256, 8, 12, (0.6, 0.7, 0.9), 45.0, (30, 18, 42), (0, 2, 0), (0, 1, 0), 0.0, 10.0)
+    sc = B.Scene(scene)
+    ref, st = sc.render(cam, 6, seed=9)
+    acc = torch.zeros((cam.image_height(), cam.image_width, 3), dtype=torch.float32, device="cuda:0")
+    sc.render_device_static(cam, 6, acc.data_ptr(), seed=9)
+    torch.cuda.synchronize()
+    assert ((acc.cpu().numpy() != ref).any(axis=2)).mean() < 1e-4
+    sc.close()
+    multi = B.MultiScene(scene, [0, 0])
+    img, mst = multi.render(cam, 6, seed=9)
+    multi.close()
+    assert mst.rays == st.rays
+    assert (np.abs(img - ref) > 1e-5 * np.maximum(1.0, np.abs(ref))).any(axis=2).mean() < 1e-4
