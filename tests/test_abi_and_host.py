@@ -607,3 +607,28 @@ def test_instance_descriptors_are_validated():
         d = bad.desc()
         out = C.c_void_p()
         assert L.rt_scene_create(C.byref(d), 0, 0, C.byref(out)) == abi.RT_ERR_ARG, edit
+
+
+def test_scene_file_roundtrip_with_instances(tmp_path):
+    """A .rtscene file carries the instance records behind the other arrays (its tenth count, zero in
+    files written before there were instances): the C writer, the C reader and the numpy reader
+    agree, and a count that does not fit the file is refused."""
+    scene, _, _ = two_level_scene()
+    p = str(tmp_path / "two_level.rtscene")
+    d = scene.desc()
+    binding.check(binding.lib().rt_scene_file_save(C.byref(d), p.encode()))
+    out = C.POINTER(abi.SceneDesc)()
+    binding.check(binding.lib().rt_scene_file_load(p.encode(), C.byref(out)))
+    assert out.contents.n_instances == len(scene.instances) == 18 and out.contents.n_prims == len(scene.prims)
+    got = np.ctypeslib.as_array(C.cast(out.contents.instances, C.POINTER(C.c_int32)), (18, 4)).copy()
+    binding.lib().rt_scene_file_free(out)
+    assert np.array_equal(got, scene.instances.view("<i4").reshape(18, 4))
+    back = abi.SceneArrays.load(p)
+    assert back.instances.tobytes() == scene.instances.tobytes() and back.prims.tobytes() == scene.prims.tobytes()
+    q = str(tmp_path / "again.rtscene")
+    back.save(q)
+    assert open(q, "rb").read() == open(p, "rb").read()
+    blob = bytearray(open(p, "rb").read())
+    blob[8 + 8 * 9:16 + 8 * 9] = (19).to_bytes(8, "little")  # one instance more than the file holds
+    open(q, "wb").write(bytes(blob))
+    assert binding.lib().rt_scene_file_load(q.encode(), C.byref(out)) == abi.RT_ERR_IO
