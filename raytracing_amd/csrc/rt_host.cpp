@@ -315,7 +315,7 @@ LaunchGeom choose_geom(rt_scene *s, uint32_t flags) {
         int bits = 1;
         while ((1ll << bits) < std::max<long long>(dv.n_nodes, 2ll * (dv.n_slots + dv.n_inst + 1))) bits++;
         dv.ref_bits = std::max(16, std::min(32, bits + 1));
-        lg.stack_lds_entries = bvh ? std::max(4, std::min(cap, env_int("RT_AMD_LDS_STACK", 24))) : 0;
+        lg.stack_lds_entries = bvh ? std::max(4, std::min(cap, env_int("RT_AMD_LDS_STACK", 16))) : 0;
         size_t stack = (size_t)lg.stack_lds_entries * RT_MEGA_MAX_THREADS * sizeof(int);
         bpc = bpc_target;
         while (bpc > 1 && lds_budget(bpc) < stack + ring_bytes) bpc--;
