@@ -253,6 +253,8 @@ typedef struct rt_scene_info {
     uint64_t device_bytes;
     float build_ms;       /* flattening + BVH build (host or device), without the upload */
     int32_t built_on_device; /* 1 if the BVH came from the device builder */
+    int32_t n_upfront;    /* primitives kept out of the tree because their box covers most of the scene
+                             (a ground sphere): every ray tests them before it walks the tree */
 } rt_scene_info;
 
 typedef struct rt_scene rt_scene; /* opaque: owns the device copy of one scene */

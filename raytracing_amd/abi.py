@@ -100,7 +100,8 @@ class RenderStats(C.Structure):
 class SceneInfo(C.Structure):
     _fields_ = [("n_prims", C.c_int32), ("n_spheres", C.c_int32), ("n_quads", C.c_int32),
                 ("n_nodes", C.c_int32), ("bvh_depth", C.c_int32), ("lds_resident", C.c_int32),
-                ("device_bytes", C.c_uint64), ("build_ms", C.c_float), ("built_on_device", C.c_int32)]
+                ("device_bytes", C.c_uint64), ("build_ms", C.c_float), ("built_on_device", C.c_int32),
+                ("n_upfront", C.c_int32)]
 
 
 class SceneArrays:

@@ -167,6 +167,12 @@ struct DevScene {
     // "slot" n_slots + k of the top tree; slot n_slots + n_inst marks the end of a visit on the stack.
     const i4 *inst;
     int n_inst;
+    // Primitives whose box covers most of the scene (a ground sphere) are not in the tree: they are
+    // slots [0, n_big) and every ray tests them before it starts its walk (bit j of big_quads: slot
+    // j is a quad).  Every ray would reach their leaf anyway; tested first, their hit culls from the
+    // first node on, and the test runs when all lanes of a wave start rays together.
+    int n_big;
+    int big_quads;
     int n_slots;
     int n_nodes;
     int n_textures;
@@ -954,6 +960,13 @@ RT_HD void trav_test_leaf(Trav &tv, int leaf_ref, const DevScene &sc, const Scen
     }
 }
 
+// The primitives that are not in the tree (DevScene::n_big), right after trav_begin.
+template <bool COUNT>
+RT_HD void trav_test_big(Trav &tv, const DevScene &sc, const SceneView &v, const Ray &r, float tmin, Cnt<COUNT> &cn) {
+    for (int j = 0; j < sc.n_big; j++)
+        trav_test_leaf<COUNT>(tv, ~(j * 2 + ((sc.big_quads >> j) & 1)), sc, v, r, tmin, cn);
+}
+
 // Two-level scenes.  A leaf whose slot lies beyond the primitives is not a primitive: slot
 // n_slots + k enters instance k (the ray goes into the sub-scene's space through the instance's
 // wrappers, a mark is left on the stack, and the walk goes on at the root of the sub-scene's
@@ -1000,6 +1013,7 @@ RT_HD TraceHit trace_bvh(const DevScene &sc, const SceneView &v, const Ray &r, f
                          const ST &st, Cnt<COUNT> &cn) {
     Trav tv;
     trav_begin(tv, r, tmax);
+    trav_test_big<COUNT>(tv, sc, v, r, tmin, cn);
     while (tv.ref != RT_TRAV_DONE) {
         if (tv.ref >= 0) {
             trav_inner<COUNT, ST, false, SPILL, NODE_F4>(tv, v.nodes, tmin, st, sc.ref_bits, cn);

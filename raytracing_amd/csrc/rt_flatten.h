@@ -28,6 +28,8 @@ const int kMaxLdsBytes = 160 * 1024;  // LDS per CU on gfx950
 const int kParallelBuildMinPrims = 65536; // scenes from this size on: subtrees built by several threads
 const int kTreeTopMin = 1280;         // trees of at least this many 128-byte nodes never fit LDS whole
 const int kTreeTopMax = 1024;         // nodes moved to the front for the LDS copy of the tree's top
+const float kBigPrimArea = 0.5f;      // a primitive whose box has this share of the scene's box area is tested up front
+const int kBigPrimMax = 4;            // ... at most this many of them
 const int kMaxInnerDepth = RT_MAX_TREE_LEVELS - 1; // of the binary tree (the root is at depth 0)
 
 // ---------------------------------------------------------------------------------------
@@ -687,6 +689,8 @@ struct HostScene {
     // two-level scenes (rt_instance): per instance {root reference of its sub-scene's tree, wrapper
     // chain, what to add to a primitive's id to order it among all primitives of the world, -}
     std::vector<i4> inst;
+    // primitives kept out of the tree and tested by every ray up front: slots [0, n_big)
+    int n_big = 0, big_quads = 0;
 };
 
 // Adds node_base to the inner references of wide nodes [first, first + count) and maps their
@@ -954,15 +958,47 @@ inline int flatten_scene(const rt_scene_desc *d, uint32_t flags, HostScene &out,
         slots = geom;
         for (int i = 0; i < n; i++) meta[i] = i4{types[i], d->prims[i].material, d->prims[i].xform, i};
     } else {
+        // Primitives whose box takes up most of the scene's (a ground sphere: every ray enters its box)
+        // stay out of the tree: they become the first slots and every ray tests them before it starts
+        // its walk (rt_core.h trav_test_big).
+        std::vector<int> big, rest;
+        {
+            Box3 all;
+            all.reset();
+            for (const Box3 &b : boxes) all.add(b);
+            const float limit = kBigPrimArea * all.area();
+            for (int i = 0; i < n; i++)
+                if ((int)big.size() < kBigPrimMax && boxes[i].area() >= limit) big.push_back(i);
+            if (n - (int)big.size() < 2 || getenv("RT_AMD_NO_BIG")) big.clear();
+            std::vector<char> is_big(n, 0);
+            for (int i : big) is_big[i] = 1;
+            for (int i = 0; i < n; i++)
+                if (!is_big[i]) rest.push_back(i);
+        }
+        const int n_big = (int)big.size(), n_rest = (int)rest.size();
+        std::vector<Box3> rest_boxes_store;
+        std::vector<int> rest_types_store;
+        const std::vector<Box3> *tb = &boxes;
+        const std::vector<int> *tt = &types;
+        if (n_big > 0) {
+            rest_boxes_store.reserve(n_rest);
+            rest_types_store.reserve(n_rest);
+            for (int i : rest) {
+                rest_boxes_store.push_back(boxes[i]);
+                rest_types_store.push_back(types[i]);
+            }
+            tb = &rest_boxes_store;
+            tt = &rest_types_store;
+        }
         BvhOut bo;
         bool built = false;
         if (external) {
-            built = external(boxes, types, bo) && (int)bo.leaf_order.size() == n &&
-                    (int)bo.nodes.size() == 4 * (n - 1) && bo.max_inner_depth <= kMaxInnerDepth;
+            built = external(*tb, *tt, bo) && (int)bo.leaf_order.size() == n_rest &&
+                    (int)bo.nodes.size() == 4 * (n_rest - 1) && bo.max_inner_depth <= kMaxInnerDepth;
             if (!built) bo = BvhOut();
         }
         if (!built) {
-            BvhBuilder builder(boxes, types);
+            BvhBuilder builder(*tb, *tt);
             bo = builder.run();
         }
         out.external_nodes = built;
@@ -971,10 +1007,14 @@ inline int flatten_scene(const rt_scene_desc *d, uint32_t flags, HostScene &out,
         nodes = std::move(wide.nodes);
         // trees too large for LDS: their top is cached there (kTreeTopMin nodes is more than a CU's LDS holds)
         out.n_top = wide.n_nodes >= kTreeTopMin ? reorder_tree_top(nodes, kTreeTopMax) : 0;
+        if (n_big > 0) relocate_wide(nodes, 0, (size_t)wide.n_nodes, 0, [&](int s0) { return n_big + s0; });
         nodes_to_plane_layout(nodes);
         slots.resize((size_t)n * slot_f4);
+        out.n_big = n_big;
+        out.big_quads = 0;
         for (int sl = 0; sl < n; sl++) {
-            int pi = bo.leaf_order[sl];
+            int pi = sl < n_big ? big[sl] : rest[bo.leaf_order[sl - n_big]];
+            if (sl < n_big && types[pi] == RT_PRIM_QUAD) out.big_quads |= 1 << sl;
             memcpy(&slots[(size_t)sl * slot_f4], &geom[(size_t)pi * slot_f4], sizeof(f4) * slot_f4);
             meta[sl] = i4{types[pi], d->prims[pi].material, d->prims[pi].xform, pi};
         }

@@ -470,6 +470,7 @@ static int impl_rt_scene_create(const rt_scene_desc *d, int device, uint32_t fla
     s->info.bvh_depth = hs.bvh_depth;
     s->info.build_ms = (float)build_ms;
     s->info.built_on_device = hs.external_nodes ? 1 : 0;
+    s->info.n_upfront = hs.n_big;
 
     const std::vector<rt_texture> &texs = hs.textures;
     std::vector<rt_image> imgs(d->images, d->images + d->n_images);
@@ -505,6 +506,8 @@ static int impl_rt_scene_create(const rt_scene_desc *d, int device, uint32_t fla
     s->d_counters = const_cast<rtc::Counters *>(dc);
     dv.n_slots = n;
     dv.n_inst = (int)hs.inst.size();
+    dv.n_big = hs.n_big;
+    dv.big_quads = hs.big_quads;
     dv.n_nodes = hs.n_nodes;
     dv.n_top = 0; // chosen with the launch geometry
     s->tree_top = hs.n_top;

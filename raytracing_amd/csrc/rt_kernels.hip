@@ -348,7 +348,10 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
             }
         }
         // scattered rays and camera rays set their traversal up together (more lanes per instruction)
-        if (begin) trav_begin(tv, ps.ray, RT_INF);
+        if (begin) {
+            trav_begin(tv, ps.ray, RT_INF);
+            trav_test_big<COUNT>(tv, sc, vw, ps.ray, 0.001f, cn);
+        }
         RT_TOCK(c_regen);
         const bool pool_dry = TAIL || (wp.exhausted && wp.k >= wp.k_end);
         if constexpr (!TAIL) {
@@ -410,6 +413,7 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
                                 pixel = __builtin_bit_cast(unsigned, a4.x);
                                 sample = __builtin_bit_cast(unsigned, a4.y);
                                 trav_begin(tv, ps.ray, RT_INF);
+                                trav_test_big<COUNT>(tv, sc, vw, ps.ray, 0.001f, cn);
                                 pend = Parked();
                                 state = ST_TRAV;
                             }
@@ -655,6 +659,7 @@ trace_sched(DevScene sc, RenderParams rp, const rt_ray *rays, long long n_rays, 
                 ray.d = mk(in.dir[0], in.dir[1], in.dir[2]);
                 ray.tm = in.tm;
                 trav_begin(tv, ray, tmax);
+                trav_test_big<false>(tv, sc, vw, ray, tmin, cn);
                 pend = Parked();
                 state = ST_TRAV;
                 want = false;

@@ -52,6 +52,8 @@ void *sim_scene_create(const rt_scene_desc *d, uint32_t flags) {
     dv.n_slots = s->hs.n_prims;
     dv.inst = s->hs.inst.data();
     dv.n_inst = (int)s->hs.inst.size();
+    dv.n_big = s->hs.n_big;
+    dv.big_quads = s->hs.big_quads;
     dv.n_nodes = s->hs.n_nodes;
     dv.slot_f4 = s->hs.slot_f4;
     dv.traversal = s->hs.linear ? TRAV_LINEAR : TRAV_BVH;

@@ -162,7 +162,7 @@ def test_tree_top_in_lds_changes_nothing(tmp_path, monkeypatch):
     info = sc.info()
     assert info.lds_resident == 0
     depth, inner, leaves, outside = _tree_stats(sc.nodes())
-    assert inner == info.n_nodes and leaves == len(arrays.prims) and depth == info.bvh_depth and outside == 0
+    assert inner == info.n_nodes and leaves == len(arrays.prims) - info.n_upfront and depth == info.bvh_depth and outside == 0
     hits = sc.trace(rays)
     a, st = sc.render(cam, 6, seed=4)
     sc.close()
@@ -290,7 +290,8 @@ def test_bvh_is_a_proper_tree(flags):
     info = sc.info()
     depth, inner, leaves, outside = _tree_stats(sc.nodes())
     assert inner == info.n_nodes and (len(arrays.prims) - 1) / 3 <= inner < len(arrays.prims) - 1
-    assert leaves == len(arrays.prims) and depth == info.bvh_depth and outside == 0
+    assert info.n_upfront == 1  # the ground sphere: every ray tests it before its walk
+    assert leaves == len(arrays.prims) - 1 and depth == info.bvh_depth and outside == 0
     sc.close()
 
 
