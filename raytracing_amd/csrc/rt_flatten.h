@@ -866,7 +866,21 @@ inline int flatten_scene(const rt_scene_desc *d, uint32_t flags, HostScene &out,
                 max_sub_levels = std::max(max_sub_levels, sub.wide.levels);
             }
         }
-        // items of the top tree: the loose primitives, then the instances
+        // loose primitives whose box takes up most of the world's are tested up front (as in the
+        // one-level case below) and become the first slots
+        std::vector<int> big;
+        {
+            Box3 all;
+            all.reset();
+            for (int i = 0; i < n; i++)
+                if (!in_template[i]) all.add(boxes[i]);
+            const float limit = kBigPrimArea * all.area();
+            for (int i = 0; i < n; i++)
+                if (!in_template[i] && (int)big.size() < kBigPrimMax && boxes[i].area() >= limit) big.push_back(i);
+            if (getenv("RT_AMD_NO_BIG")) big.clear();
+            for (int i : big) in_template[i] = 2; // (neither in a sub-scene nor an item of the top tree)
+        }
+        // items of the top tree: the other loose primitives, then the instances
         std::vector<Box3> ib;
         std::vector<int> it, item_prim;
         for (int i = 0; i < n; i++)
@@ -909,6 +923,12 @@ inline int flatten_scene(const rt_scene_desc *d, uint32_t flags, HostScene &out,
         }
         // final slots
         std::vector<int> item_slot(n_items, -1), slot_prim;
+        out.n_big = (int)big.size();
+        out.big_quads = 0;
+        for (size_t j = 0; j < big.size(); j++) {
+            slot_prim.push_back(big[j]);
+            if (types[big[j]] == RT_PRIM_QUAD) out.big_quads |= 1 << j;
+        }
         for (int item : top_order)
             if (item < n_loose) {
                 item_slot[item] = (int)slot_prim.size();
