@@ -1,3 +1,5 @@
+#!/bin/bash
+# GPU box: throughput of bouncing_spheres against the samples per launch (how much the end of a launch costs).
 set -e
 mkdir -p gpurun_out/asym
 for spp in 100 400 1600; do
