@@ -10,7 +10,12 @@ context the model gives 39 instructions per ray with 38 / 44 / 26 lanes per node
 phase / leaf batch (measured: 35.4 and 37 / 40 / 26).  With two contexts node steps run with
 48-51 lanes, and the instructions per ray fall to 34.5 if an exchange of contexts costs 40
 instructions per block and to 37.1 if it costs 70 (17 registers moved, and the new ray's
-traversal set-up inside the node loop): 5-12 % for 17 more live registers.  Not built.
+traversal set-up inside the node loop): 5-12 % for 17 more live registers.
+
+Measured later: such a kernel was built (same images, 109 VGPRs) and ran 10-20 % SLOWER than the
+one-context kernel at every setting of its thresholds, so the model is too kind: it prices an
+exchange and a ray's start per block, but those blocks run with the few lanes that have just
+finished, and it leaves out the extra scheduling decisions.  The kernel was removed again.
 """
 import numpy as np
 rng = np.random.default_rng(1)
