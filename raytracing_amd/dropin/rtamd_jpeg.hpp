@@ -132,24 +132,29 @@ inline int fx(double x) { return (int)(x * 4096 + 0.5); }
 
 // One 8-point pass on in[0..7] (stride 1 here; callers gather).  Produces the even part e[0..3]
 // and the odd part o[0..3], both scaled by 2^12; output k is e[k] + o[3-k] ... (see idct8x8).
-inline void idct_1d(const int s[8], int e[4], int o[4]) {
-    static const int c0541 = fx(0.5411961f), c1847 = fx(-1.847759065f), c0765 = fx(0.765366865f);
-    static const int c1175 = fx(1.175875602f), c0298 = fx(0.298631336f), c2053 = fx(2.053119869f);
-    static const int c3072 = fx(3.072711026f), c1501 = fx(1.501321110f), c0899 = fx(-0.899976223f);
-    static const int c2562 = fx(-2.562915447f), c1961 = fx(-1.961570560f), c0390 = fx(-0.390180644f);
+// The arithmetic is done modulo 2^32: a valid file stays far inside 32 bits (same values as
+// with int), and a damaged one, whose coefficients can be anything, wraps instead of running
+// into signed overflow.
+typedef uint32_t u32;
+inline u32 fxu(double x) { return (u32)fx(x); }
+inline void idct_1d(const u32 s[8], u32 e[4], u32 o[4]) {
+    static const u32 c0541 = fxu(0.5411961f), c1847 = fxu(-1.847759065f), c0765 = fxu(0.765366865f);
+    static const u32 c1175 = fxu(1.175875602f), c0298 = fxu(0.298631336f), c2053 = fxu(2.053119869f);
+    static const u32 c3072 = fxu(3.072711026f), c1501 = fxu(1.501321110f), c0899 = fxu(-0.899976223f);
+    static const u32 c2562 = fxu(-2.562915447f), c1961 = fxu(-1.961570560f), c0390 = fxu(-0.390180644f);
     // even part: rotation of (s2, s6), butterflies with (s0, s4)
-    int z = (s[2] + s[6]) * c0541;
-    int r2 = z + s[6] * c1847;
-    int r3 = z + s[2] * c0765;
-    int a = (s[0] + s[4]) * 4096, b = (s[0] - s[4]) * 4096;
+    u32 z = (s[2] + s[6]) * c0541;
+    u32 r2 = z + s[6] * c1847;
+    u32 r3 = z + s[2] * c0765;
+    u32 a = (s[0] + s[4]) * 4096u, b = (s[0] - s[4]) * 4096u;
     e[0] = a + r3;
     e[3] = a - r3;
     e[1] = b + r2;
     e[2] = b - r2;
     // odd part
-    int q0 = s[7], q1 = s[5], q2 = s[3], q3 = s[1];
-    int w3 = q0 + q2, w4 = q1 + q3, w1 = q0 + q3, w2 = q1 + q2;
-    int w5 = (w3 + w4) * c1175;
+    u32 q0 = s[7], q1 = s[5], q2 = s[3], q3 = s[1];
+    u32 w3 = q0 + q2, w4 = q1 + q3, w1 = q0 + q3, w2 = q1 + q2;
+    u32 w5 = (w3 + w4) * c1175;
     q0 *= c0298;
     q1 *= c2053;
     q2 *= c3072;
@@ -163,28 +168,30 @@ inline void idct_1d(const int s[8], int e[4], int o[4]) {
     o[1] = q1 + w2 + w4;
     o[0] = q0 + w1 + w3;
 }
+// arithmetic shift of a value kept modulo 2^32
+inline int sar(u32 v, int n) { return (int32_t)v >> n; }
 
 // coef: 64 dequantised coefficients in natural order; out: 8 rows of 8 samples
 inline void idct8x8(const short coef[64], uint8_t *out, int out_stride) {
-    int mid[64];
+    u32 mid[64];
     for (int c = 0; c < 8; c++) { // columns; 2 fractional bits are kept
-        int s[8], e[4], o[4];
-        for (int k = 0; k < 8; k++) s[k] = coef[k * 8 + c];
+        u32 s[8], e[4], o[4];
+        for (int k = 0; k < 8; k++) s[k] = (u32)(int)coef[k * 8 + c];
         idct_1d(s, e, o);
         for (int k = 0; k < 4; k++) {
-            int ev = e[k] + 512;
-            mid[k * 8 + c] = (ev + o[3 - k]) >> 10;
-            mid[(7 - k) * 8 + c] = (ev - o[3 - k]) >> 10;
+            u32 ev = e[k] + 512u;
+            mid[k * 8 + c] = (u32)sar(ev + o[3 - k], 10);
+            mid[(7 - k) * 8 + c] = (u32)sar(ev - o[3 - k], 10);
         }
     }
     for (int r = 0; r < 8; r++) { // rows; 2^17 to remove, level shift folded into the rounding
-        int e[4], o[4];
+        u32 e[4], o[4];
         idct_1d(mid + r * 8, e, o);
         uint8_t *dst = out + r * out_stride;
         for (int k = 0; k < 4; k++) {
-            int ev = e[k] + 65536 + (128 << 17);
-            dst[k] = clamp_u8((ev + o[3 - k]) >> 17);
-            dst[7 - k] = clamp_u8((ev - o[3 - k]) >> 17);
+            u32 ev = e[k] + 65536u + (128u << 17);
+            dst[k] = clamp_u8(sar(ev + o[3 - k], 17));
+            dst[7 - k] = clamp_u8(sar(ev - o[3 - k], 17));
         }
     }
 }
@@ -213,8 +220,8 @@ inline bool prog_dc(BitReader &br, const HuffTable &hd, Component &c, short *blk
         int t = decode_symbol(br, hd);
         if (t < 0 || t > 15) return false;
         int diff = t ? extend(br.bits(t), t) : 0;
-        c.dc_pred += diff;
-        blk[0] = (short)(c.dc_pred * (1 << sc.al));
+        c.dc_pred = (int)((u32)c.dc_pred + (u32)diff); // (a damaged file may wrap)
+        blk[0] = (short)((u32)c.dc_pred * (1u << sc.al));
     } else if (br.bit()) {
         blk[0] = (short)(blk[0] + (short)(1 << sc.al));
     }
@@ -392,8 +399,8 @@ inline bool decode_scan(const uint8_t *data, size_t size, size_t &pos, std::vect
         int t = decode_symbol(br, hd);
         if (t < 0 || t > 15) return (*why = "bad DC code", false);
         int diff = t ? extend(br.bits(t), t) : 0;
-        c.dc_pred += diff;
-        block[0] = (short)(c.dc_pred * q[0]);
+        c.dc_pred = (int)((u32)c.dc_pred + (u32)diff); // (a damaged file may wrap)
+        block[0] = (short)((u32)c.dc_pred * (u32)q[0]);
         for (int k = 1; k < 64;) {
             int rs = decode_symbol(br, ha);
             if (rs < 0) return (*why = "bad AC code", false);

@@ -104,6 +104,43 @@ def test_truncated_progressive_jpeg_does_not_crash(tmp_path):
         assert r.returncode in (0, 1), (cut, r.returncode, r.stderr[-200:])
 
 
+def test_idct_of_a_damaged_file_wraps_instead_of_overflowing(tmp_path):
+    """A damaged file can hold any 16-bit coefficients; the inverse transform then runs modulo
+    2^32 (no signed overflow: -fsanitize=undefined stays silent), and blocks a real file can hold
+    come out as before (a flat block of DC 8*v gives 128 + v everywhere)."""
+    src = tmp_path / "idct_extremes.cpp"
+    src.write_text(r"""
+#include "rtamd_jpeg.hpp"
+#include <cstdio>
+int main() {
+    using rtamd::jpeg::detail::idct8x8;
+    short c[64];
+    uint8_t out[64];
+    unsigned sum = 0;
+    const short ext[4] = {32767, -32768, 32767, -1};
+    for (int pat = 0; pat < 6; pat++) {
+        for (int i = 0; i < 64; i++) c[i] = pat < 4 ? ext[(i * (pat + 1) + pat) & 3] : (short)((i * 7919 + pat * 104729) * 2654435761u >> 16);
+        idct8x8(c, out, 8);
+        for (int i = 0; i < 64; i++) sum += out[i];
+    }
+    for (int v = -128; v < 128; v += 17) {
+        for (int i = 0; i < 64; i++) c[i] = 0;
+        c[0] = (short)(8 * v);
+        idct8x8(c, out, 8);
+        for (int i = 0; i < 64; i++)
+            if (out[i] != 128 + v) { std::printf("flat block %d: %d\n", v, out[i]); return 1; }
+    }
+    std::printf("ok %u\n", sum);
+    return 0;
+}
+""")
+    exe = str(tmp_path / "idct_extremes")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                    "-I" + os.path.join(ROOT, "raytracing_amd", "dropin"), str(src), "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and r.stdout.startswith("ok") and "runtime error" not in r.stderr, r.stdout + r.stderr
+
+
 def test_missing_image_is_not_fatal(tmp_path):
     """rtw_stb_image.h:42 / texture.h:62: a missing texture file prints an error and the
     texture renders blue; the scene still flattens (image = -1)."""
