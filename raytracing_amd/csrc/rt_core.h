@@ -1139,7 +1139,9 @@ RT_HD f3 texture_value(const DevScene &sc, const SceneView &vw, int tex, const S
         int xi = int(floorf(t.scale * s.p.x));
         int yi = int(floorf(t.scale * s.p.y));
         int zi = int(floorf(t.scale * s.p.z));
-        bool is_even = (xi + yi + zi) % 2 == 0;
+        // (x + y + z) % 2 == 0 of texture.h:45 by the sum's lowest bit, which a sum that leaves the
+        // range of int keeps
+        bool is_even = (((unsigned)xi + (unsigned)yi + (unsigned)zi) & 1u) == 0u;
         t = vw.textures[is_even ? t.even : t.odd];
     }
     if (t.type == RT_TEX_SOLID) return mk(t.color[0], t.color[1], t.color[2]);

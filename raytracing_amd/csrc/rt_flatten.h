@@ -178,6 +178,16 @@ void pad_box(Box3 &b) {
         b.lo[k] -= pad;
         b.hi[k] += pad;
     }
+    // A primitive with a coordinate that is not a number, infinite or beyond 3e37 (the reference
+    // never hits one either) gets a box that spans everything along that axis: the builders then
+    // only ever see finite, ordered numbers (their sorts and bins rely on that), every ray is sent
+    // to the primitive's exact test, and that test decides as it would have anyway.
+    const float kHuge = 3e37f;
+    for (int k = 0; k < 3; k++)
+        if (!(b.lo[k] >= -kHuge && b.hi[k] <= kHuge && b.lo[k] <= b.hi[k])) {
+            b.lo[k] = -kHuge;
+            b.hi[k] = kHuge;
+        }
 }
 
 // Centre and half extent of a box; centre - half <= lo and centre + half >= hi hold exactly.
@@ -255,6 +265,7 @@ inline Wide collapse_to_wide(const std::vector<f4> &bin) {
         const int l = child_ref(n, 0), r = child_ref(n, 1);
         Cost &c = cost[n];
         float best = INFINITY;
+        c.node_split = 2; // (kept when every cost is infinite: boxes beyond the range of float areas)
         for (int k = 1; k <= 3; k++) {
             float v = sub(l, k) + sub(r, 4 - k);
             if (v < best) {
