@@ -287,6 +287,8 @@ int rt_camera_initialize(const rt_camera_desc *c, rt_camera_frame *f) { // camer
     if (!c || !f) return fail(RT_ERR_ARG, "null camera");
     if (c->image_width < 1 || c->samples_per_pixel < 1 || !(c->aspect_ratio > 0.0f))
         return fail(RT_ERR_ARG, "camera: image_width, samples_per_pixel and aspect_ratio must be positive");
+    if (!((double)c->image_width / (double)c->aspect_ratio < 1073741824.0)) // (camera.h:77 converts it to int)
+        return fail(RT_ERR_ARG, "camera: image_width / aspect_ratio = %g is no image height", (double)c->image_width / (double)c->aspect_ratio);
     rtf::camera_frame(c, f);
     return RT_OK;
 }

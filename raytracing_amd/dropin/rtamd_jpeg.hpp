@@ -560,6 +560,13 @@ inline bool decode(const uint8_t *data, size_t size, Image &img, std::string *er
             if (nc == 1) comp[0].h = comp[0].v = h_max = v_max = 1; // a lone component is not interleaved
             mcus_x = (width + 8 * h_max - 1) / (8 * h_max);
             mcus_y = (height + 8 * v_max - 1) / (8 * v_max);
+            // A few header bytes can claim 65535 x 65535 samples (tens of GB of planes).  Every coded
+            // block takes at least one bit, so a large image in a file that cannot hold a bit per
+            // block is refused before anything is allocated; small images are decoded whatever the
+            // file's length (a cut file gives a partly grey picture, as with stb_image).
+            if ((uint64_t)width * (uint64_t)height > (64ull << 20) &&
+                (uint64_t)mcus_x * (uint64_t)mcus_y > 8ull * (uint64_t)size)
+                return fail("the image size in the header is implausible for the file's length");
             for (Component &c : comp) {
                 c.x = (width * c.h + h_max - 1) / h_max;
                 c.y = (height * c.v + v_max - 1) / v_max;

@@ -104,6 +104,23 @@ def test_truncated_progressive_jpeg_does_not_crash(tmp_path):
         assert r.returncode in (0, 1), (cut, r.returncode, r.stderr[-200:])
 
 
+def test_jpeg_header_claiming_a_huge_image_is_refused_before_allocating(tmp_path):
+    """Four bytes of the frame header set to 65535 x 65535 in a 2 KB file: tens of GB of planes if
+    taken at its word.  Refused with a message (and quickly), not an allocation failure."""
+    import time
+    _ensure_built()
+    raw = bytearray(open(os.path.join(JPEG_DIR, "prog_gray.jpg"), "rb").read())
+    i = raw.index(b"\xff\xc2")
+    raw[i + 5:i + 9] = b"\xff\xff\xff\xff"
+    src = tmp_path / "huge.jpg"
+    src.write_bytes(bytes(raw))
+    t0 = time.time()
+    r = subprocess.run([os.path.join(BIN, "rt_image"), str(src), str(tmp_path / "o.rtimg")], capture_output=True,
+                       text=True, timeout=60)
+    assert r.returncode == 1 and "implausible" in r.stderr, r.stderr[-300:]
+    assert time.time() - t0 < 10
+
+
 def test_idct_of_a_damaged_file_wraps_instead_of_overflowing(tmp_path):
     """A damaged file can hold any 16-bit coefficients; the inverse transform then runs modulo
     2^32 (no signed overflow: -fsanitize=undefined stays silent), and blocks a real file can hold
