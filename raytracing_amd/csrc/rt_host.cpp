@@ -76,39 +76,48 @@ const int kMaxLdsBytes = 160 * 1024 - RT_BLOCK_POOL_BYTES; // LDS per CU on gfx9
 } // namespace
 
 // ---------------------------------------------------------------------------------------
+// Record sets that pipelined launches rotate through (rt_scene), and each set's counter words
+constexpr int kSets = 3;
+constexpr int kPoolWord[kSets] = {0, 2, 8};
+constexpr int kBatchWord[kSets] = {4, 5, 9};
+
 struct rt_scene {
     int device = 0;
     rtc::DevScene dev;
     rt_scene_info info;
     std::vector<void *> allocs;
     // render scratch (owned by the scene, grown on demand)
-    // two sets of per-launch scratch: consecutive megakernel launches go to two internal
-    // streams, so that launch k+1 fills the CUs that the tail of launch k (its last long
-    // paths) leaves idle; the reduction into the caller's image stays on the caller's stream
-    f4 *stage[2] = {nullptr, nullptr};
-    size_t stage_bytes[2] = {0, 0};
-    hipStream_t mega_stream[2] = {nullptr, nullptr};
-    hipEvent_t ev_done[2] = {nullptr, nullptr}; // megakernel finished (recorded on its internal stream)
-    hipEvent_t ev_free[2] = {nullptr, nullptr}; // the set's records have been reduced (caller's stream)
-    bool ev_free_valid[2] = {false, false};
+    // kSets sets of per-launch scratch: consecutive megakernel launches go to internal streams
+    // of their own, so that launch k+1 fills the CUs that the tail of launch k (its last long
+    // paths) leaves idle; the reduction into the caller's image stays on the caller's stream.
+    // The third set keeps launch k+2 from waiting for the reduction of launch k, which itself
+    // cannot start before launch k+1 (whose workgroups fill every CU) begins to leave.
+    f4 *stage[kSets] = {};
+    size_t stage_bytes[kSets] = {};
+    hipStream_t mega_stream[kSets] = {};
+    hipEvent_t ev_done[kSets] = {}; // megakernel finished (recorded on its internal stream)
+    hipEvent_t ev_free[kSets] = {}; // the set's records have been reduced (caller's stream)
+    bool ev_free_valid[kSets] = {};
     int flip = 0;
     // tail hand-over of pipelined launches (RenderParams::spill): per set, the batches and their counts
-    f4 *spill[2] = {nullptr, nullptr};
-    unsigned *spill_count[2] = {nullptr, nullptr};
+    f4 *spill[kSets] = {};
+    unsigned *spill_count[kSets] = {};
     int spill_waves = 0, spill_max = 0;
     unsigned epoch = 0;
     // cost-ordered strips (per record set): reduce_stage leaves a cost per 64-pixel strip, sorted
     // into the order in which the set's next launch of the same image hands the strips out
-    unsigned *strip_cost[2] = {nullptr, nullptr}, *strip_order[2] = {nullptr, nullptr};
-    unsigned strip_valid[2] = {0, 0}; // strips the order covers (0: none yet)
+    unsigned *strip_cost[kSets] = {}, *strip_order[kSets] = {};
+    unsigned strip_valid[kSets] = {}; // strips the order covers (0: none yet)
     unsigned *strip_iota = nullptr, *strip_sorted = nullptr;
     void *strip_tmp = nullptr;
     size_t strip_tmp_bytes = 0;
     unsigned strip_cap = 0;
     // scenes read from HBM with a tree too deep for the LDS part of the stacks: the rest of every
     // lane's stack, one buffer per record set and one for rt_render_device_static
-    int *stack_spill[3] = {nullptr, nullptr, nullptr};
-    unsigned long long *d_words = nullptr; // [0] pool counter, [1] ray counter
+    int *stack_spill[kSets + 1] = {};
+    // counters: word 1 counts rays, 6 is the batch query's pool counter; per record set a pool counter
+    // (kPoolWord) and the tail hand-over's batch counter (kBatchWord)
+    unsigned long long *d_words = nullptr;
     rtc::Counters *d_counters = nullptr;
     int n_cu = 256;
     int tree_top = 0; // HostScene::n_top: how many leading nodes are the most visited ones
@@ -298,7 +307,7 @@ int rt_scene_destroy(rt_scene *s) {
     hipSetDevice(s->device);
     for (void *p : s->allocs) hipFree(p);
     hipDeviceSynchronize();
-    for (int b = 0; b < 2; b++) {
+    for (int b = 0; b < kSets; b++) {
         if (s->stage[b]) hipFree(s->stage[b]);
         if (s->strip_cost[b]) hipFree(s->strip_cost[b]);
         if (s->strip_order[b]) hipFree(s->strip_order[b]);
@@ -411,7 +420,7 @@ static int impl_rt_scene_create(const rt_scene_desc *d, int device, uint32_t fla
     if (rc == RT_OK) rc = upload(s, hs.perlins, &dv.perlins);
     if (rc == RT_OK) rc = upload(s, imgs, &dv.images);
     if (rc == RT_OK) rc = upload(s, texels, &dv.texels);
-    std::vector<unsigned long long> words(8, 0ull); // 0 / 2: pool counters, 1: rays, 4 / 5: batch counters
+    std::vector<unsigned long long> words(16, 0ull);
     const unsigned long long *dw = nullptr;
     if (rc == RT_OK) rc = upload(s, words, &dw);
     std::vector<rtc::Counters> cnt(1);
@@ -458,7 +467,7 @@ static int impl_rt_scene_create(const rt_scene_desc *d, int device, uint32_t fla
     s->geom = choose_geom(s, flags);
     if (s->geom.stack_cap > s->geom.stack_lds_entries) {
         const size_t bytes = (size_t)(s->geom.stack_cap - s->geom.stack_lds_entries) * s->geom.grid * RT_MEGA_MAX_THREADS * sizeof(int);
-        for (int k = 0; k < 3; k++) {
+        for (int k = 0; k < kSets + 1; k++) {
             void *p = nullptr;
             if (hipMalloc(&p, bytes) != hipSuccess) {
                 rt_scene_destroy(s);
@@ -533,7 +542,7 @@ int ensure_wavefront(rt_scene *s, unsigned n_slots) {
 
 // Knobs of the render kernels' scheduling, read from the environment once per call.
 struct Tunables {
-    int scheduler, pipeline, spill_max, tail_blocks, unit_order, strip_order;
+    int scheduler, pipeline, sets, spill_max, tail_blocks, unit_order, strip_order;
     int min_ready, leaf_min, blocked_min, regen_min;
     bool timeline;
 };
@@ -541,11 +550,13 @@ Tunables read_tunables(bool lds_scene) {
     Tunables t;
     t.scheduler = env_int("RT_AMD_SCHEDULER", 1) != 0 ? 1 : 0; // BVH scenes: 1 = decoupled (default), 0 = whole ray
     t.pipeline = env_int("RT_AMD_PIPELINE", 1);
+    t.sets = std::min(kSets, std::max(2, env_int("RT_AMD_SETS", kSets))); // record sets that pipelined launches rotate through
     // Tail hand-over: a wave down to spill_max paths gives them to one of tail_blocks server
-    // workgroups.  Servers are the last to leave their CUs, which the next launch is waiting for:
-    // measured on overlapped launches, 8 paths and 8 servers beat 16 / 16 by 4 % when the scene is
-    // in LDS (a CU holds one workgroup at a time); HBM scenes are flat within 1.5 %.
-    t.spill_max = std::max(0, std::min(64, env_int("RT_AMD_SPILL_MAX", 8)));
+    // workgroups and leaves.  Off by default: it paid (4 %) while launch k+2 had to wait for the
+    // reduction of launch k; with three record sets the next launches' workgroups are already
+    // waiting for every CU a launch gives up, and leaving the last paths where they are is
+    // 2.5 % faster on scenes held in LDS (scenes read from HBM: no difference).
+    t.spill_max = std::max(0, std::min(64, env_int("RT_AMD_SPILL_MAX", 0)));
     t.tail_blocks = env_int("RT_AMD_TAIL_BLOCKS", lds_scene ? 8 : 16);
     t.unit_order = env_int("RT_AMD_UNIT_ORDER", 1);
     t.strip_order = env_int("RT_AMD_STRIP_ORDER", lds_scene ? 1 : 0);
@@ -701,7 +712,7 @@ static int impl_rt_render_device(rt_scene *s, const rt_camera_desc *cam, const r
     for (int done = 0; done < opts->sample_count; done += chunk) {
         int sc_n = std::min(chunk, opts->sample_count - done);
         const int b = pipelined ? s->flip : 0;
-        if (pipelined) s->flip ^= 1;
+        if (pipelined) s->flip = (s->flip + 1) % tn.sets;
         rc = ensure_stage(b);
         if (rc != RT_OK) return rc;
         // every launch leaves an event behind that says "this record set has been reduced"
@@ -718,7 +729,7 @@ static int impl_rt_render_device(rt_scene *s, const rt_camera_desc *cam, const r
             const int waves = lg.grid * (lg.block / 64);
             if (want_spill > 0 && s->dev.traversal == rtc::TRAV_BVH && scheduler == 1 &&
                 (s->spill_waves < waves || s->spill_max < want_spill)) {
-                for (int k = 0; k < 2; k++) {
+                for (int k = 0; k < kSets; k++) {
                     if (s->spill[k]) RT_HIP(hipFree(s->spill[k]));
                     if (s->spill_count[k]) RT_HIP(hipFree(s->spill_count[k]));
                     s->spill[k] = nullptr;
@@ -736,9 +747,9 @@ static int impl_rt_render_device(rt_scene *s, const rt_camera_desc *cam, const r
             // only the scene and writes only this set)
             if (s->ev_free_valid[b]) RT_HIP(hipStreamWaitEvent(ms, s->ev_free[b], 0));
         } else {
-            // set 0 on the caller's stream: whatever used either set last must be through with it
-            // (set 1 too: the strip costs and the ray counter are shared with it)
-            for (int k = 0; k < 2; k++)
+            // set 0 on the caller's stream: whatever used any set last must be through with it
+            // (the others too: the strip costs and the ray counter are shared with them)
+            for (int k = 0; k < kSets; k++)
                 if (s->ev_free_valid[k]) RT_HIP(hipStreamWaitEvent(stream, s->ev_free[k], 0));
         }
         RenderParams rp = base_params(W, H, n_pixels, opts, done, sc_n, lg, tn);
@@ -748,7 +759,7 @@ static int impl_rt_render_device(rt_scene *s, const rt_camera_desc *cam, const r
         if (strip_costs) {
             if (rp.n_strips > s->strip_cap) {
                 RT_HIP(hipDeviceSynchronize());
-                for (int k = 0; k < 2; k++) {
+                for (int k = 0; k < kSets; k++) {
                     if (s->strip_cost[k]) RT_HIP(hipFree(s->strip_cost[k]));
                     if (s->strip_order[k]) RT_HIP(hipFree(s->strip_order[k]));
                     s->strip_cost[k] = s->strip_order[k] = nullptr;
@@ -773,7 +784,7 @@ static int impl_rt_render_device(rt_scene *s, const rt_camera_desc *cam, const r
         }
         rp.stage = s->stage[b];
         rp.stack_spill = s->stack_spill[b];
-        rp.next_chunk = reinterpret_cast<unsigned *>(s->d_words + 2 * b); // words 0 / 2: pool counters, 1: rays
+        rp.next_chunk = reinterpret_cast<unsigned *>(s->d_words + kPoolWord[b]);
         rp.counters = count ? s->d_counters : nullptr;
         if (pipelined && s->spill[b] && s->dev.traversal == rtc::TRAV_BVH && scheduler == 1) {
             const int servers = std::max(1, std::min(lg.grid / 4, tn.tail_blocks));
@@ -783,11 +794,11 @@ static int impl_rt_render_device(rt_scene *s, const rt_camera_desc *cam, const r
                 if (s->epoch == 0) s->epoch = 1;
                 rp.spill = s->spill[b];
                 rp.spill_count = s->spill_count[b];
-                rp.next_batch = reinterpret_cast<unsigned *>(s->d_words + 4 + b);
+                rp.next_batch = reinterpret_cast<unsigned *>(s->d_words + kBatchWord[b]);
                 rp.epoch = s->epoch;
                 rp.spill_max = want_spill;
                 rp.n_server_blocks = servers;
-                RT_HIP(hipMemsetAsync(s->d_words + 4 + b, 0, sizeof(unsigned long long), ms));
+                RT_HIP(hipMemsetAsync(s->d_words + kBatchWord[b], 0, sizeof(unsigned long long), ms));
             }
         }
         if (!wavefront && scheduler == 1 && s->dev.traversal == rtc::TRAV_BVH && tn.timeline) {
@@ -801,7 +812,7 @@ static int impl_rt_render_device(rt_scene *s, const rt_camera_desc *cam, const r
             if (waves == s->timeline_waves)
                 rp.timeline = s->d_timeline + (size_t)(s->timeline_launches++ % kTimelineLaunches) * waves * 4;
         }
-        RT_HIP(hipMemsetAsync(s->d_words + 2 * b, 0, sizeof(unsigned long long), ms));
+        RT_HIP(hipMemsetAsync(s->d_words + kPoolWord[b], 0, sizeof(unsigned long long), ms));
         EventPair prof;
         if (s->profiling) {
             rc = prof.create();
@@ -922,7 +933,7 @@ static int impl_rt_render_device_static(rt_scene *s, const rt_camera_desc *cam, 
         const int sc_n = std::min(chunk, opts->sample_count - done);
         RenderParams rp = base_params(W, H, n_pixels, opts, done, sc_n, lg, tn);
         rp.stage = stage;
-        rp.stack_spill = s->stack_spill[2]; // (allocated with the scene, not here)
+        rp.stack_spill = s->stack_spill[kSets]; // (allocated with the scene, not here)
         rp.next_chunk = reinterpret_cast<unsigned *>(words);
         // the block keeps the last call's contents: the counters must start at zero
         RT_HIP(hipMemsetAsync(words, 0, 2 * sizeof(unsigned long long), stream));
@@ -986,7 +997,7 @@ int rt_trace_batch_sched_device(rt_scene *s, const rt_ray *d_rays, int64_t n, fl
     if (rc != RT_OK) return rc;
     hipStream_t stream = (hipStream_t)stream_v;
     // record set 0's stack overflow area and a spare counter word: order behind whatever used them
-    for (int k = 0; k < 2; k++)
+    for (int k = 0; k < kSets; k++)
         if (s->ev_free_valid[k]) RT_HIP(hipStreamWaitEvent(stream, s->ev_free[k], 0));
     const LaunchGeom lg = s->geom;
     const Tunables tn = read_tunables(lg.lds_scene);

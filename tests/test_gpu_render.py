@@ -241,19 +241,26 @@ def test_render_argument_errors():
 
 
 def test_pipelined_launches_equal_serial_ones(monkeypatch):
-    """rt_render_device without statistics sends consecutive megakernel launches to two internal
-    streams (launch k+1 starts in the tail of launch k).  The accumulated image must be the one
-    the same calls give with RT_AMD_PIPELINE=0, bit for bit, also when launches are chunked and
-    when a statistics call comes in between."""
+    """rt_render_device without statistics sends consecutive megakernel launches to internal
+    streams, rotating through three sets of per-launch records (launch k+1 starts in the tail of
+    launch k, and launch k+2 does not wait for the reduction of launch k).  The accumulated image
+    must be the one the same calls give with RT_AMD_PIPELINE=0, bit for bit, also when launches are
+    chunked and when a statistics call comes in between; the same with two record sets, and with
+    the tail hand-over between waves switched on (off by default)."""
     import torch
     B = _binding()
     arrays, cam, _ = load_scene("bouncing_spheres")
     cam.image_width = 160
     H, W = cam.image_height(), cam.image_width
     results = []
-    for pipeline in ("1", "0"):
+    for pipeline, sets, spill in (("0", None, None), ("1", None, None), ("1", "2", None), ("1", "2", "8"), ("1", "3", "8")):
         monkeypatch.setenv("RT_AMD_PIPELINE", pipeline)
         monkeypatch.setenv("RT_AMD_STAGE_MB", "1")   # 160*90*16 B per sample -> 4 samples per launch
+        for name, value in (("RT_AMD_SETS", sets), ("RT_AMD_SPILL_MAX", spill)):
+            if value is None:
+                monkeypatch.delenv(name, raising=False)
+            else:
+                monkeypatch.setenv(name, value)
         sc = B.Scene(arrays)
         acc = torch.zeros(H, W, 3, device="cuda")
         stream = torch.cuda.current_stream().cuda_stream
@@ -267,8 +274,9 @@ def test_pipelined_launches_equal_serial_ones(monkeypatch):
         torch.cuda.synchronize()
         results.append(acc.cpu().numpy())
         sc.close()
-    assert np.array_equal(results[0], results[1])
     assert results[0].mean() > 0
+    for r in results[1:]:
+        assert np.array_equal(results[0], r)
 
 
 def test_serial_wavefront_and_pipelined_calls_alternate_without_host_syncs():
@@ -296,7 +304,7 @@ def test_serial_wavefront_and_pipelined_calls_alternate_without_host_syncs():
             elif kind == 2:    # wavefront variant (caller's stream, record set 0)
                 sc.render_device(cam, count, acc.data_ptr(), stream=stream, sample_begin=begin, seed=4,
                                  mode=abi.RT_MODE_WAVEFRONT)
-            else:              # pipelined (internal streams, sets 0 / 1 in turn)
+            else:              # pipelined (internal streams, the record sets in turn)
                 sc.render_device(cam, count, acc.data_ptr(), stream=stream, sample_begin=begin, seed=4)
             begin += count
             if sync_each:
