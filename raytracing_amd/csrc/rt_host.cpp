@@ -77,9 +77,13 @@ const int kMaxLdsBytes = 160 * 1024 - RT_BLOCK_POOL_BYTES; // LDS per CU on gfx9
 
 // ---------------------------------------------------------------------------------------
 // Record sets that pipelined launches rotate through (rt_scene), and each set's counter words
-constexpr int kSets = 3;
-constexpr int kPoolWord[kSets] = {0, 2, 8};
-constexpr int kBatchWord[kSets] = {4, 5, 9};
+#ifndef RT_SETS
+#define RT_SETS 3
+#endif
+constexpr int kSets = RT_SETS;
+static_assert(kSets >= 2 && kSets <= 4, "two to four record sets");
+constexpr int kPoolWord[4] = {0, 2, 8, 10};
+constexpr int kBatchWord[4] = {4, 5, 9, 11};
 
 struct rt_scene {
     int device = 0;
