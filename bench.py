@@ -420,6 +420,12 @@ def main():
     ap.add_argument("--cpu-paths", type=float, default=13.5e6, help="paths of the CPU baseline sample")
     args = ap.parse_args()
 
+    # Four hardware queues per process (HIP's default) are one too few once RCCL's streams join the
+    # library's four: two render streams then share a queue and their launches cannot overlap
+    # (7.4 instead of 8.3 Gpaths/s per GPU).  Must be set before anything initialises HIP; the
+    # ranks started below inherit it.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # no launcher: start the ranks from here.  Nothing in this process has touched the GPU
         # (counting devices does not initialise it).

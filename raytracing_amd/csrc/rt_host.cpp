@@ -83,7 +83,6 @@ const int kMaxLdsBytes = 160 * 1024 - RT_BLOCK_POOL_BYTES; // LDS per CU on gfx9
 constexpr int kSets = RT_SETS;
 static_assert(kSets >= 2 && kSets <= 4, "two to four record sets");
 constexpr int kPoolWord[4] = {0, 2, 8, 10};
-constexpr int kBatchWord[4] = {4, 5, 9, 11};
 
 struct rt_scene {
     int device = 0;
@@ -103,11 +102,6 @@ struct rt_scene {
     hipEvent_t ev_free[kSets] = {}; // the set's records have been reduced (caller's stream)
     bool ev_free_valid[kSets] = {};
     int flip = 0;
-    // tail hand-over of pipelined launches (RenderParams::spill): per set, the batches and their counts
-    f4 *spill[kSets] = {};
-    unsigned *spill_count[kSets] = {};
-    int spill_waves = 0, spill_max = 0;
-    unsigned epoch = 0;
     // cost-ordered strips (per record set): reduce_stage leaves a cost per 64-pixel strip, sorted
     // into the order in which the set's next launch of the same image hands the strips out
     unsigned *strip_cost[kSets] = {}, *strip_order[kSets] = {};
@@ -120,7 +114,7 @@ struct rt_scene {
     // lane's stack, one buffer per record set and one for rt_render_device_static
     int *stack_spill[kSets + 1] = {};
     // counters: word 1 counts rays, 6 is the batch query's pool counter; per record set a pool counter
-    // (kPoolWord) and the tail hand-over's batch counter (kBatchWord)
+    // (kPoolWord)
     unsigned long long *d_words = nullptr;
     rtc::Counters *d_counters = nullptr;
     int n_cu = 256;
@@ -288,6 +282,15 @@ int set_device(int device) {
 extern "C" {
 
 const char *rt_last_error(void) { return g_err.c_str(); }
+// A process has four hardware queues per GPU by default, shared by all of its streams.  A scene
+// uses four streams itself (three internal ones and the caller's); with a communication library's
+// streams in the same process two of the internal ones end up on one queue, where launches cannot
+// overlap (measured: 7.4 instead of 8.3 Gpaths/s with RCCL initialised).  Eight queues are enough.
+// This only helps if the library is loaded before the HIP runtime reads its settings (a C++
+// program linked against it; Python harnesses set the variable themselves before importing torch),
+// and never overrides a value the user has set.
+__attribute__((constructor)) static void rt_amd_more_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 int rt_abi_version(void) { return RT_AMD_ABI_VERSION; }
 
 int rt_device_count(void) {
@@ -315,8 +318,6 @@ int rt_scene_destroy(rt_scene *s) {
         if (s->stage[b]) hipFree(s->stage[b]);
         if (s->strip_cost[b]) hipFree(s->strip_cost[b]);
         if (s->strip_order[b]) hipFree(s->strip_order[b]);
-        if (s->spill[b]) hipFree(s->spill[b]);
-        if (s->spill_count[b]) hipFree(s->spill_count[b]);
         if (s->mega_stream[b]) hipStreamDestroy(s->mega_stream[b]);
         if (s->ev_done[b]) hipEventDestroy(s->ev_done[b]);
         if (s->ev_free[b]) hipEventDestroy(s->ev_free[b]);
@@ -550,7 +551,7 @@ int ensure_wavefront(rt_scene *s, unsigned n_slots) {
 
 // Knobs of the render kernels' scheduling, read from the environment once per call.
 struct Tunables {
-    int scheduler, pipeline, sets, spill_max, tail_blocks, unit_order, strip_order;
+    int scheduler, pipeline, sets, unit_order, strip_order;
     int min_ready, leaf_min, blocked_min, regen_min;
     bool timeline;
 };
@@ -559,13 +560,6 @@ Tunables read_tunables(bool lds_scene) {
     t.scheduler = env_int("RT_AMD_SCHEDULER", 1) != 0 ? 1 : 0; // BVH scenes: 1 = decoupled (default), 0 = whole ray
     t.pipeline = env_int("RT_AMD_PIPELINE", 1);
     t.sets = std::min(kSets, std::max(2, env_int("RT_AMD_SETS", kSets))); // record sets that pipelined launches rotate through
-    // Tail hand-over: a wave down to spill_max paths gives them to one of tail_blocks server
-    // workgroups and leaves.  Off by default: it paid (4 %) while launch k+2 had to wait for the
-    // reduction of launch k; with three record sets the next launches' workgroups are already
-    // waiting for every CU a launch gives up, and leaving the last paths where they are is
-    // 2.5 % faster on scenes held in LDS (scenes read from HBM: no difference).
-    t.spill_max = std::max(0, std::min(64, env_int("RT_AMD_SPILL_MAX", 0)));
-    t.tail_blocks = env_int("RT_AMD_TAIL_BLOCKS", lds_scene ? 8 : 16);
     t.unit_order = env_int("RT_AMD_UNIT_ORDER", 1);
     t.strip_order = env_int("RT_AMD_STRIP_ORDER", lds_scene ? 1 : 0);
     t.min_ready = std::max(1, std::min(64, env_int("RT_AMD_MIN_READY", 48)));
@@ -577,7 +571,7 @@ Tunables read_tunables(bool lds_scene) {
 }
 
 // The fields of RenderParams every launch has: image, sample range, units, scheduling knobs.
-// Everything optional (strip order, tail hand-over, counters, timeline) starts switched off.
+// Everything optional (strip order, counters, timeline) starts switched off.
 RenderParams base_params(int W, int H, int n_pixels, const rt_render_opts *opts, int done, int sc_n,
                                 const LaunchGeom &lg, const Tunables &tn) {
     RenderParams rp;
@@ -732,24 +726,6 @@ static int impl_rt_render_device(rt_scene *s, const rt_camera_desc *cam, const r
                 RT_HIP(hipEventCreateWithFlags(&s->ev_done[b], hipEventDisableTiming));
             }
             ms = s->mega_stream[b];
-            // tail hand-over: only BVH scenes with the decoupled scheduler have it
-            const int want_spill = tn.spill_max;
-            const int waves = lg.grid * (lg.block / 64);
-            if (want_spill > 0 && s->dev.traversal == rtc::TRAV_BVH && scheduler == 1 &&
-                (s->spill_waves < waves || s->spill_max < want_spill)) {
-                for (int k = 0; k < kSets; k++) {
-                    if (s->spill[k]) RT_HIP(hipFree(s->spill[k]));
-                    if (s->spill_count[k]) RT_HIP(hipFree(s->spill_count[k]));
-                    s->spill[k] = nullptr;
-                    s->spill_count[k] = nullptr;
-                    RT_HIP(hipMalloc((void **)&s->spill[k], (size_t)waves * want_spill * RT_SPILL_F4 * sizeof(f4)));
-                    RT_HIP(hipMalloc((void **)&s->spill_count[k], (size_t)waves * sizeof(unsigned)));
-                    RT_HIP(hipMemset(s->spill_count[k], 0, (size_t)waves * sizeof(unsigned)));
-                }
-                s->spill_waves = waves;
-                s->spill_max = want_spill;
-                s->epoch = 0;
-            }
             // this set's previous records must have been reduced (by a pipelined call or by one
             // that kept to its caller's stream); nothing else orders the render kernel (it reads
             // only the scene and writes only this set)
@@ -794,21 +770,6 @@ static int impl_rt_render_device(rt_scene *s, const rt_camera_desc *cam, const r
         rp.stack_spill = s->stack_spill[b];
         rp.next_chunk = reinterpret_cast<unsigned *>(s->d_words + kPoolWord[b]);
         rp.counters = count ? s->d_counters : nullptr;
-        if (pipelined && s->spill[b] && s->dev.traversal == rtc::TRAV_BVH && scheduler == 1) {
-            const int servers = std::max(1, std::min(lg.grid / 4, tn.tail_blocks));
-            const int want_spill = std::min(s->spill_max, tn.spill_max);
-            if (want_spill > 0 && lg.grid > servers) {
-                s->epoch = (s->epoch + 1) & 0xffffffu;
-                if (s->epoch == 0) s->epoch = 1;
-                rp.spill = s->spill[b];
-                rp.spill_count = s->spill_count[b];
-                rp.next_batch = reinterpret_cast<unsigned *>(s->d_words + kBatchWord[b]);
-                rp.epoch = s->epoch;
-                rp.spill_max = want_spill;
-                rp.n_server_blocks = servers;
-                RT_HIP(hipMemsetAsync(s->d_words + kBatchWord[b], 0, sizeof(unsigned long long), ms));
-            }
-        }
         if (!wavefront && scheduler == 1 && s->dev.traversal == rtc::TRAV_BVH && tn.timeline) {
             const int waves = lg.grid * (lg.block / 64);
             if (!s->d_timeline) {

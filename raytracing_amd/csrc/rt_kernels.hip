@@ -226,15 +226,7 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
     Trav tv;
     unsigned pixel = 0, sample = 0, n_rays = 0;
     Cnt<COUNT> cn;
-    // tail hand-over (RenderParams::spill_max): producers give their last paths away, servers take them
-    const int spill_max = rp.spill_max;
     const int waves_per_block = blockDim.x >> 6;
-    const bool is_server = spill_max > 0 && (int)blockIdx.x < rp.n_server_blocks;
-    const int producer = ((int)blockIdx.x - rp.n_server_blocks) * waves_per_block + (threadIdx.x >> 6);
-    const unsigned n_producers = (unsigned)((int)gridDim.x - rp.n_server_blocks) * (unsigned)waves_per_block;
-    bool batches_done = !is_server; // no batch left to claim
-    bool have_batch = false;
-    unsigned batch = 0;
     // wave-level schedule statistics (instrumented variant only), kept by lane 0
     unsigned long long w_s_phases = 0, w_s_lanes = 0;
     SchedStats ss;
@@ -248,9 +240,8 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
 #define RT_TOCK(acc) if constexpr (COUNT) acc += clock64() - c_mark
 
     // The wave's loop exists twice: the first copy runs while the launch still has new paths to
-    // hand out and contains nothing of the tail hand-over (its registers and branches cost the
-    // main phase a few per cent of VALU instructions even when they do nothing); the second copy
-    // takes over when the pool has run dry, and contains no code that starts paths.
+    // hand out; the second copy takes over when the pool has run dry, and contains no code that
+    // starts paths.
     auto run_phase = [&](auto tail_tag) {
     constexpr bool TAIL = decltype(tail_tag)::value;
     for (;;) {
@@ -357,80 +348,8 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
         if constexpr (!TAIL) {
             if (pool_dry) return; // on to the tail copy of the loop
         }
-        if (TAIL && spill_max > 0) {
-            if (!is_server) {
-                // ---- producer: down to a few paths, hand them over and leave ------------------------
-                unsigned long long live = __ballot(state == ST_TRAV);
-                int n_live = __popcll(live);
-                if (n_live <= spill_max && !__any(state == ST_READY)) {
-                    if (state == ST_TRAV) { // the ray is traced again from its origin by the server
-                        f4 *rec = rp.spill + ((size_t)producer * spill_max + __popcll(live & lane_mask_lt)) * RT_SPILL_F4;
-                        rec[0] = f4{ps.ray.o.x, ps.ray.o.y, ps.ray.o.z, ps.ray.tm};
-                        rec[1] = f4{ps.ray.d.x, ps.ray.d.y, ps.ray.d.z, 0.0f};
-                        rec[2] = f4{ps.beta.x, ps.beta.y, ps.beta.z, __builtin_bit_cast(float, ps.rng.s)};
-                        rec[3] = f4{ps.L.x, ps.L.y, ps.L.z,
-                                    __builtin_bit_cast(float, ((unsigned)ps.depth & 0xffffu) | (n_rays << 16))};
-                        rec[4] = f4{__builtin_bit_cast(float, pixel), __builtin_bit_cast(float, sample), 0.0f, 0.0f};
-                    }
-                    __threadfence(); // the records are visible before the count says so
-                    if (lane == 0)
-                        __hip_atomic_store(&rp.spill_count[producer], (rp.epoch << 8) | (unsigned)n_live, __ATOMIC_RELEASE,
-                                           __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-            } else if (!batches_done) {
-                // ---- server: take the next producer's batch once spill_max lanes are free -----------
-                unsigned long long idle = __ballot(state == ST_IDLE);
-                if (__popcll(idle) >= spill_max) {
-                    if (!have_batch) {
-                        unsigned b = 0;
-                        if (lane == 0) b = atomicAdd(rp.next_batch, 1u);
-                        batch = wave_bcast32(b);
-                        have_batch = true;
-                        if (batch >= n_producers) batches_done = true;
-                    }
-                    if (!batches_done) {
-                        unsigned v = 0;
-                        if (lane == 0)
-                            v = __hip_atomic_load(&rp.spill_count[batch], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-                        v = wave_bcast32(v);
-                        if ((v >> 8) == rp.epoch) { // that wave has left: its batch is complete
-                            __threadfence();
-                            const int n_rec = (int)(v & 0xffu);
-                            const int r = __popcll(idle & lane_mask_lt);
-                            if (state == ST_IDLE && r < n_rec) {
-                                const f4 *rec = rp.spill + ((size_t)batch * spill_max + r) * RT_SPILL_F4;
-                                const f4 a0 = rec[0], a1 = rec[1], a2 = rec[2], a3 = rec[3], a4 = rec[4];
-                                ps.ray.o = mk(a0.x, a0.y, a0.z);
-                                ps.ray.tm = a0.w;
-                                ps.ray.d = mk(a1.x, a1.y, a1.z);
-                                ps.beta = mk(a2.x, a2.y, a2.z);
-                                ps.rng.s = __builtin_bit_cast(unsigned, a2.w);
-                                ps.L = mk(a3.x, a3.y, a3.z);
-                                const unsigned packed = __builtin_bit_cast(unsigned, a3.w);
-                                ps.depth = (int)(packed & 0xffffu);
-                                n_rays = packed >> 16;
-                                pixel = __builtin_bit_cast(unsigned, a4.x);
-                                sample = __builtin_bit_cast(unsigned, a4.y);
-                                trav_begin(tv, ps.ray, RT_INF);
-                                trav_test_big<COUNT>(tv, sc, vw, ps.ray, 0.001f, cn);
-                                pend = Parked();
-                                state = ST_TRAV;
-                            }
-                            have_batch = false;
-                        } else if (!__any(state != ST_IDLE)) {
-                            __builtin_amdgcn_s_sleep(32); // nothing else to do: wait for that wave
-                        }
-                    }
-                }
-            }
-        }
         if (!__any(state != ST_IDLE)) {
-            if (pool_dry && batches_done) {
-                if (spill_max > 0 && !is_server && lane == 0) // a producer that finished everything itself
-                    __hip_atomic_store(&rp.spill_count[producer], rp.epoch << 8, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
+            if (pool_dry) break;
             continue;
         }
         // ---- traversal steps until enough lanes wait for shading ------------------------------

@@ -10,7 +10,6 @@
 #define RT_MEGA_WAVES_PER_SIMD 4
 #endif
 #define RT_TRACE_THREADS 256
-#define RT_SPILL_F4 5            // 80-byte records of paths handed over at the tail of a launch
 #ifndef RT_POOL_MAX_UNITS
 #define RT_POOL_MAX_UNITS 32u // a workgroup reserves at most this many units of 64 paths at a time
 #endif
@@ -45,16 +44,6 @@ struct RenderParams {
     int leaf_min;  // decoupled: lanes that must hold a parked leaf before the leaf block runs
     int blocked_min; // decoupled: ... or this many lanes stalled on a second leaf
     int regen_min;   // decoupled: idle lanes that must accumulate before new paths are started
-    // Tail hand-over of the decoupled kernel (spill_max > 0): once the launch has no new paths
-    // left, a wave of a block >= n_server_blocks that is down to spill_max live paths writes
-    // them to its batch in `spill` and exits, so that its CU is free for the next launch; the
-    // waves of the first n_server_blocks blocks pick the batches up and finish them.
-    rtc::f4 *spill;          // [producer wave][spill_max] path records of RT_SPILL_F4 x 16 bytes
-    unsigned *spill_count;   // [producer wave] (epoch << 8) | records, written once when the wave exits
-    unsigned *next_batch;    // next batch to hand to a server wave, zeroed before the launch
-    unsigned epoch;          // distinguishes this launch's spill_count entries from older ones
-    int spill_max;
-    int n_server_blocks;
     // Debugging aid (non-null): every wave of the decoupled kernel leaves {start, out of new
     // paths, exit} in 100 MHz wall-clock ticks and its hardware id, 4 x 8 bytes per wave.
     unsigned long long *timeline;

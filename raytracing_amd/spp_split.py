@@ -45,16 +45,21 @@ def render_split(render_fn, accum, spp_total, dst=0, group=None):
 
 class SplitPipeline:
     """render_split for a sequence of frames with the reduce of frame k overlapping the render
-    of frame k + 1: two accumulation images used in turn, the collective issued asynchronously
-    (with the nccl backend it runs on the communicator's own stream, ordered after the render
-    that filled its image; the next frame renders into the other image meanwhile).  An image
-    is reused only after the reduce that read it has been waited for.  `finish()` waits for
+    of the frames after it: three accumulation images used in turn, the collective issued
+    asynchronously (with the nccl backend it runs on the communicator's own stream, ordered
+    after the render that filled its image; the next frames render into the other images
+    meanwhile).  An image is reused only after the reduce that read it has been waited for.
+    Three images, like the library's three record sets: the render kernels of the next frame
+    fill every CU, so the collective's kernel gets its turn only when that frame begins to
+    leave, and the frame after it must not have to wait for that.  `finish()` waits for
     everything and returns the image of the last frame (complete on rank `dst`)."""
+
+    N_IMAGES = 3
 
     def __init__(self, render_fn, shape, device, dst=0, group=None):
         self.render_fn, self.dst, self.group = render_fn, dst, group
-        self.images = [torch.zeros(shape, dtype=torch.float32, device=device) for _ in range(2)]
-        self.pending = [None, None]
+        self.images = [torch.zeros(shape, dtype=torch.float32, device=device) for _ in range(self.N_IMAGES)]
+        self.pending = [None] * self.N_IMAGES
         self.k = 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -62,7 +67,7 @@ class SplitPipeline:
     def frame(self, spp_total, begin_count=None):
         """One frame of spp_total samples per pixel over all ranks (or this rank's explicit
         (begin, count)).  Returns the image the frame is accumulated in."""
-        b = self.k & 1
+        b = self.k % self.N_IMAGES
         self.k += 1
         if self.pending[b] is not None:
             self.pending[b].wait()
@@ -77,11 +82,11 @@ class SplitPipeline:
         return img
 
     def finish(self):
-        for b in range(2):
+        for b in range(self.N_IMAGES):
             if self.pending[b] is not None:
                 self.pending[b].wait()
                 self.pending[b] = None
-        return self.images[(self.k - 1) & 1] if self.k else self.images[0]
+        return self.images[(self.k - 1) % self.N_IMAGES] if self.k else self.images[0]
 
 
 def gpu_render_fn(scene, cam, seed=0, overlap=True):

@@ -245,18 +245,17 @@ def test_pipelined_launches_equal_serial_ones(monkeypatch):
     streams, rotating through three sets of per-launch records (launch k+1 starts in the tail of
     launch k, and launch k+2 does not wait for the reduction of launch k).  The accumulated image
     must be the one the same calls give with RT_AMD_PIPELINE=0, bit for bit, also when launches are
-    chunked and when a statistics call comes in between; the same with two record sets, and with
-    the tail hand-over between waves switched on (off by default)."""
+    chunked and when a statistics call comes in between; the same with two record sets."""
     import torch
     B = _binding()
     arrays, cam, _ = load_scene("bouncing_spheres")
     cam.image_width = 160
     H, W = cam.image_height(), cam.image_width
     results = []
-    for pipeline, sets, spill in (("0", None, None), ("1", None, None), ("1", "2", None), ("1", "2", "8"), ("1", "3", "8")):
+    for pipeline, sets in (("0", None), ("1", None), ("1", "2"), ("1", "3")):
         monkeypatch.setenv("RT_AMD_PIPELINE", pipeline)
         monkeypatch.setenv("RT_AMD_STAGE_MB", "1")   # 160*90*16 B per sample -> 4 samples per launch
-        for name, value in (("RT_AMD_SETS", sets), ("RT_AMD_SPILL_MAX", spill)):
+        for name, value in (("RT_AMD_SETS", sets),):
             if value is None:
                 monkeypatch.delenv(name, raising=False)
             else:

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """GPU box: many launches of one scene, every image compared with the first.
 
-Looks for what a short test cannot: a race that shows once in thousands of launches (the tail
-hand-over between waves, the two record sets of overlapped launches, the path pool).  Every launch
+Looks for what a short test cannot: a race that shows once in thousands of launches (the record
+sets of overlapped launches, the path pool, the cost-ordered strips).  Every launch
 renders the same samples into a zeroed image; images must be equal bit for bit, except for the
 known schedule-dependent "phantom" hits far from small spheres (a pixel in a million on scenes
 that have them), which are counted and reported.
