@@ -173,6 +173,9 @@ struct DevScene {
     // first node on, and the test runs when all lanes of a wave start rays together.
     int n_big;
     int big_quads;
+    // Largest diagonal of a tree leaf's box, in the units of the world-space ray direction (the host
+    // scales it where wrappers change lengths): the absolute part of the culling slack (Trav::cull_t).
+    float cull_len;
     int n_slots;
     int n_nodes;
     int n_textures;
@@ -321,6 +324,26 @@ RT_HD bool sphere_test(f4 g0, f4 g1, f3 o, f3 d, float a, float tm, float tmin, 
     }
     t_out = root;
     return true;
+}
+
+// True if the point of the ray closest to the sphere's centre lies inside the sphere's own box
+// (centre +- radius, grown by a margin that is well inside the padding of the tree's boxes).  Far
+// from a small sphere the discriminant of sphere.h:47-52 is dominated by rounding, and a ray that
+// passes the sphere at more than its radius can still be reported as hitting it, at about the
+// parameter of its closest approach.  When that ray only clips a corner of the sphere's box, the
+// reported parameter can lie in front of the box by up to the box's size, and whether a tree walk
+// finds such a hit then depends on what else it has found by the time it reaches the box.  Hits
+// of a real intersection always pass (their closest point lies inside the sphere); the tree
+// traversal drops the others, so that every hit it reports lies inside its leaf's box up to the
+// rounding that Trav::cull_t allows for.
+RT_HD bool sphere_approach_in_box(f4 g0, f4 g1, f3 o, f3 d, float a, float tm) {
+    f3 center = xyz(g0) + tm * xyz(g1);
+    f3 oc = center - o;
+    float tc = dot(d, oc) / a;
+    f3 cp = tc * d - oc;
+    float m = fmaxf(fmaxf(fabsf(center.x), fabsf(center.y)), fabsf(center.z));
+    float half = __builtin_fmaf(m, 7e-6f, fabsf(g0.w) * 1.003f);
+    return fabsf(cp.x) <= half && fabsf(cp.y) <= half && fabsf(cp.z) <= half;
 }
 
 // quad::hit + is_interior (quad.h:38-69, 80-91).  The interval is closed.
@@ -701,9 +724,20 @@ template <typename T, int STRIDE = 0> struct TravStack {
 // for its slowest ray.  ref >= 0: inner node; ref < 0: leaf (~ref = slot*2 + type);
 // RT_TRAV_DONE: finished.
 #define RT_TRAV_DONE ((int)0x80000000)
+// Relative part of the culling slack (2^-9).  The root sphere.h:47-60 computes is off by up to
+// sqrt(k eps) |oc| / |d| near a silhouette (k: a handful of roundings of terms of size |oc|^2 |d|^2 in
+// the discriminant; eps = 2^-24: about 1e-3 of the distance), so a primitive's reported hit can lie
+// that far in front of its own box.
+#define RT_CULL_REL 1.953125e-3f
 struct Trav {
     BoxRay br;
     float best_t;
+    // Boxes are culled against cull_t = best_t (1 + RT_CULL_REL) + cull_abs, not against best_t: a box
+    // that is dropped then lies so far beyond the closest hit so far that no primitive inside it can
+    // report a parameter before it, rounding included.  The closest hit is then the closest over ALL
+    // primitives whose boxes the ray meets, whatever the order and the moment in which leaves are
+    // tested (lanes of the decoupled kernels walk on past leaves they have not tested yet).
+    float cull_t, cull_abs;
     int best_slot;
     int ref;
     int sp; // entries on the stack, times the stride
@@ -714,10 +748,22 @@ struct Trav {
     f3 io, id;     // inside an instance: the ray in the sub-scene's space (taken there once, on entry)
     float idd;     // ... and |d|^2 there
 };
-RT_HD void trav_begin(Trav &tv, const Ray &r, float tmax) {
+RT_HD float rsqrt_approx(float x) { // only feeds slacks: 1 ulp is plenty
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rsqf(x);
+#else
+    return 1.0f / sqrtf(x);
+#endif
+}
+RT_HD float cull_bound(float best_t, float cull_abs) { return __builtin_fmaf(best_t, 1.0f + RT_CULL_REL, cull_abs); }
+RT_HD void trav_begin(Trav &tv, const Ray &r, float tmax, const DevScene &sc) {
     tv.br = make_box_ray(r);
     tv.dd = len2(r.d);
     tv.best_t = tmax;
+    // (a direction of length 0 or a non-finite one makes the product inf or NaN: fminf turns both into a
+    // huge finite slack, which culls nothing)
+    tv.cull_abs = fminf(RT_CULL_REL * sc.cull_len * rsqrt_approx(tv.dd), 3.0e38f);
+    tv.cull_t = cull_bound(tmax, tv.cull_abs);
     tv.best_slot = -1;
     tv.best_is_quad = false;
     tv.ref = 0; // root
@@ -872,10 +918,10 @@ RT_HD void trav_inner(Trav &tv, const f4 *nodes, float tmin, const ST &st, int r
     if constexpr (COUNT) cn.box += np.n_children;
     const f4 px = np.px, qx = np.qx, py = np.py, qy = np.qy, pz = np.pz, qz = np.qz, q6 = np.refs;
     float e0, e1, e2, e3;
-    const bool h0 = box_hit_planes(px.x, py.x, pz.x, qx.x, qy.x, qz.x, tv.br, tmin, tv.best_t, e0);
-    const bool h1 = box_hit_planes(px.y, py.y, pz.y, qx.y, qy.y, qz.y, tv.br, tmin, tv.best_t, e1);
-    const bool h2 = box_hit_planes(px.z, py.z, pz.z, qx.z, qy.z, qz.z, tv.br, tmin, tv.best_t, e2);
-    const bool h3 = box_hit_planes(px.w, py.w, pz.w, qx.w, qy.w, qz.w, tv.br, tmin, tv.best_t, e3);
+    const bool h0 = box_hit_planes(px.x, py.x, pz.x, qx.x, qy.x, qz.x, tv.br, tmin, tv.cull_t, e0);
+    const bool h1 = box_hit_planes(px.y, py.y, pz.y, qx.y, qy.y, qz.y, tv.br, tmin, tv.cull_t, e1);
+    const bool h2 = box_hit_planes(px.z, py.z, pz.z, qx.z, qy.z, qz.z, tv.br, tmin, tv.cull_t, e2);
+    const bool h3 = box_hit_planes(px.w, py.w, pz.w, qx.w, qy.w, qz.w, tv.br, tmin, tv.cull_t, e3);
     const unsigned hi = ref_bits >= 32 ? 0u : ~((1u << ref_bits) - 1u); // the bits of a key that hold the distance
     // (the keys first, then the selects: a key built inside the conditional would become a branch)
     const unsigned u0 = key_of(hi, e0, q6.x), u1 = key_of(hi, e1, q6.y), u2 = key_of(hi, e2, q6.z), u3 = key_of(hi, e3, q6.w);
@@ -940,6 +986,8 @@ RT_HD void trav_test_leaf(Trav &tv, int leaf_ref, const DevScene &sc, const Scen
         h = sphere_test(g[0], g[1], o, d, dd, r.tm, tmin, RT_INF, t);
         if constexpr (COUNT) cn.sphh += h ? 1 : 0;
         h = h && t <= tv.best_t;
+        // (primitives tested up front are never culled: their hits stand as computed)
+        if (h && s >= sc.n_big) h = sphere_approach_in_box(g[0], g[1], o, d, dd, r.tm);
     } else {
         RT_COUNT(quad);
         h = quad_test(g[0], g[1], g[2], g[3], o, d, tmin, tv.best_t, t);
@@ -953,6 +1001,7 @@ RT_HD void trav_test_leaf(Trav &tv, int leaf_ref, const DevScene &sc, const Scen
         }
         if (take) {
             tv.best_t = t;
+            tv.cull_t = cull_bound(t, tv.cull_abs);
             tv.best_slot = s;
             tv.best_is_quad = is_quad;
             if (RT_FEAT_INSTANCE) tv.best_inst = tv.cur_inst;
@@ -1012,7 +1061,7 @@ template <bool COUNT, class ST, bool SPILL = false, int NODE_F4 = RT_NODE_F4>
 RT_HD TraceHit trace_bvh(const DevScene &sc, const SceneView &v, const Ray &r, float tmin, float tmax,
                          const ST &st, Cnt<COUNT> &cn) {
     Trav tv;
-    trav_begin(tv, r, tmax);
+    trav_begin(tv, r, tmax, sc);
     trav_test_big<COUNT>(tv, sc, v, r, tmin, cn);
     while (tv.ref != RT_TRAV_DONE) {
         if (tv.ref >= 0) {

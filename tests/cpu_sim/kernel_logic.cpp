@@ -11,6 +11,8 @@
 
 #include <algorithm>
 #include <cstring>
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 using namespace rtc;
@@ -54,6 +56,7 @@ void *sim_scene_create(const rt_scene_desc *d, uint32_t flags) {
     dv.n_inst = (int)s->hs.inst.size();
     dv.n_big = s->hs.n_big;
     dv.big_quads = s->hs.big_quads;
+    dv.cull_len = s->hs.cull_len;
     dv.n_nodes = s->hs.n_nodes;
     dv.slot_f4 = s->hs.slot_f4;
     dv.traversal = s->hs.linear ? TRAV_LINEAR : TRAV_BVH;
@@ -139,6 +142,105 @@ void sim_trace_batch(void *scene, const rt_ray *rays, long long n, float tmin, f
     }
     if (box_tests) *box_tests = cn.box;
     if (prim_tests) *prim_tests = (unsigned long long)cn.sph + cn.quad;
+}
+
+// Certificate that the closest hit does not depend on the schedule.  The decoupled kernels test a
+// leaf an arbitrary number of node steps after they have popped it, so the best_t a box is culled
+// against varies from launch to launch between "nothing found yet" and "everything found".  For
+// each ray: walk the tree without any culling by best_t, remembering for every leaf the largest
+// entry parameter on its path from the root; test every leaf reached; the winner (and whatever ties
+// with it) must then survive the box test against its OWN parameter on every box of its path: no
+// best_t a schedule can produce is smaller than that, so no schedule can cull it.
+//   out[0]: rays whose winner some schedule could cull (with the slack of Trav::cull_t)
+//   out[1]: the same count if boxes were culled against best_t itself (no slack)
+//   out[2]: rays whose winner differs from the whole-ray traversal's
+//   out[3]: leaves reached per ray without culling, summed
+// One-level scenes only (returns -1 otherwise).
+int sim_schedule_certificate(void *scene, const rt_ray *rays, long long n, float tmin, float tmax,
+                             unsigned long long *out) {
+    SimScene *s = (SimScene *)scene;
+    const DevScene &sc = s->dev;
+    if (sc.traversal != TRAV_BVH || sc.n_inst > 0) return -1;
+    const SceneView vw = global_view(sc);
+    SimStacks stacks(sc);
+    Cnt<false> cn;
+    out[0] = out[1] = out[2] = out[3] = 0;
+    struct Leaf {
+        int ref;
+        float pme;
+    };
+    std::vector<Leaf> leaves;
+    struct Item {
+        int ref;
+        float pme;
+    };
+    std::vector<Item> todo;
+    for (long long k = 0; k < n; k++) {
+        Ray r;
+        r.o = mk(rays[k].orig[0], rays[k].orig[1], rays[k].orig[2]);
+        r.d = mk(rays[k].dir[0], rays[k].dir[1], rays[k].dir[2]);
+        r.tm = rays[k].tm;
+        Trav tv;
+        trav_begin(tv, r, tmax, sc);
+        trav_test_big<false>(tv, sc, vw, r, tmin, cn);
+        const float up_front_t = tv.best_t; // (tested before the walk in every schedule)
+        leaves.clear();
+        todo.clear();
+        todo.push_back(Item{0, -RT_INF});
+        while (!todo.empty()) {
+            const Item it = todo.back();
+            todo.pop_back();
+            if (it.ref < 0) {
+                leaves.push_back(Leaf{it.ref, it.pme});
+                continue;
+            }
+            const NodePlanes np = node_planes_global<false>(sc.nodes + (size_t)it.ref * RT_NODE_F4, tv.br);
+            const float px[4] = {np.px.x, np.px.y, np.px.z, np.px.w}, qx[4] = {np.qx.x, np.qx.y, np.qx.z, np.qx.w};
+            const float py[4] = {np.py.x, np.py.y, np.py.z, np.py.w}, qy[4] = {np.qy.x, np.qy.y, np.qy.z, np.qy.w};
+            const float pz[4] = {np.pz.x, np.pz.y, np.pz.z, np.pz.w}, qz[4] = {np.qz.x, np.qz.y, np.qz.z, np.qz.w};
+            const float rf[4] = {np.refs.x, np.refs.y, np.refs.z, np.refs.w};
+            for (int c = 0; c < 4; c++) {
+                float e;
+                // (culled against the up-front primitives' hit only: every schedule has that one)
+                if (box_hit_planes(px[c], py[c], pz[c], qx[c], qy[c], qz[c], tv.br, tmin,
+                                   cull_bound(up_front_t, tv.cull_abs), e))
+                    todo.push_back(Item{__builtin_bit_cast(int, rf[c]), e > it.pme ? e : it.pme});
+            }
+        }
+        out[3] += leaves.size();
+        // every leaf on its own, then all of them in sequence (the tie rules make the order irrelevant)
+        std::vector<float> own_t(leaves.size(), RT_INF);
+        for (size_t j = 0; j < leaves.size(); j++) {
+            Trav one = tv;
+            const int before = one.best_slot;
+            const float before_t = one.best_t;
+            trav_test_leaf<false>(one, leaves[j].ref, sc, vw, r, tmin, cn);
+            if (one.best_slot != before || one.best_t != before_t) own_t[j] = one.best_t;
+            trav_test_leaf<false>(tv, leaves[j].ref, sc, vw, r, tmin, cn);
+        }
+        bool risky = false, risky_no_slack = false;
+        for (size_t j = 0; j < leaves.size(); j++)
+            if (own_t[j] == tv.best_t && tv.best_slot >= sc.n_big) {
+                const float wide = 1.0f + 1.9073486328125e-6f; // (box_hit_planes' own widening)
+                if (!(leaves[j].pme <= __builtin_fmaf(cull_bound(tv.best_t, tv.cull_abs), wide, tv.br.e2))) {
+                    risky = true;
+                    if (getenv("SIM_CERT_DEBUG"))
+                        fprintf(stderr, "ray %lld: t %.9g path-max entry %.9g bound %.9g |d| %.6g cull_abs %.6g slot %d o (%g %g %g) d (%g %g %g)\n",
+                                k, tv.best_t, leaves[j].pme, cull_bound(tv.best_t, tv.cull_abs), sqrtf(tv.dd), tv.cull_abs,
+                                tv.best_slot, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z);
+                    if (getenv("SIM_CERT_DEBUG")) {
+                        const f4 *g = vw.slots + slot_words(sc, tv.best_slot);
+                        fprintf(stderr, "   quad %d  g0 (%g %g %g %g) g1 (%g %g %g %g)\n", (int)tv.best_is_quad, g[0].x, g[0].y, g[0].z, g[0].w, g[1].x, g[1].y, g[1].z, g[1].w);
+                    }
+                }
+                if (!(leaves[j].pme <= __builtin_fmaf(tv.best_t, wide, tv.br.e2))) risky_no_slack = true;
+            }
+        out[0] += risky;
+        out[1] += risky_no_slack;
+        const TraceHit h = sim_trace_bvh<false>(sc, vw, r, tmin, tmax, stacks, cn);
+        if (h.slot != tv.best_slot || (h.slot >= 0 && h.t != tv.best_t)) out[2]++;
+    }
+    return 0;
 }
 
 // Same per-path code as the megakernel, one path after the other.

@@ -27,6 +27,8 @@ def lib():
         L.sim_render.argtypes = [C.c_void_p, C.POINTER(abi.CameraDesc), C.c_int, C.c_int, C.c_uint32,
                                  C.c_void_p, C.POINTER(C.c_ulonglong)]
         L.sim_set_stack_mode.argtypes = [C.c_int]
+        L.sim_schedule_certificate.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_float, C.c_float,
+                                               C.POINTER(C.c_ulonglong)]
         _lib = L
     return _lib
 
@@ -65,6 +67,16 @@ class SimScene:
         lib().sim_trace_batch(self.handle, rays.ctypes.data, len(rays), tmin, tmax, hits.ctypes.data,
                               C.byref(b), C.byref(p))
         return hits, b.value, p.value
+
+    def schedule_certificate(self, rays, tmin=0.001, tmax=np.inf):
+        """(rays whose closest hit some schedule of the decoupled kernels could lose, the same count
+        without the culling slack, rays that differ from the whole-ray traversal, leaves reached)."""
+        rays = np.ascontiguousarray(rays, abi.RAY_DT)
+        out = (C.c_ulonglong * 4)()
+        rc = lib().sim_schedule_certificate(self.handle, rays.ctypes.data, len(rays), tmin, tmax, out)
+        if rc != 0:
+            raise RuntimeError("one-level BVH scenes only")
+        return tuple(int(v) for v in out)
 
     def render(self, cam, sample_count, sample_begin=0, seed=0):
         H, W = cam.image_height(), cam.image_width

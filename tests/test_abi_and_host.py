@@ -205,6 +205,60 @@ def test_kernel_logic_bvh_never_drops_a_hit():
         S.set_stack_mode(0)
 
 
+def _rays_through_a_sphere_field(n, seed, reach):
+    """Origins `reach` away, aimed into the field of small spheres at ground level."""
+    rng = np.random.default_rng(seed)
+    rays = np.zeros(n, abi.RAY_DT)
+    o = rng.normal(size=(n, 3))
+    o /= np.linalg.norm(o, axis=1, keepdims=True)
+    o *= rng.uniform(0.2 * reach, reach, size=(n, 1))
+    o[:, 1] = np.abs(o[:, 1]) * 0.3 + 0.05
+    tgt = np.stack([rng.uniform(-11, 11, n), rng.uniform(0, 1.0, n), rng.uniform(-11, 11, n)], 1)
+    rays["orig"], rays["dir"], rays["tm"] = o, (tgt - o) * rng.uniform(0.2, 3, size=(n, 1)), rng.uniform(0, 1, n)
+    return rays
+
+
+def test_kernel_logic_closest_hit_does_not_depend_on_the_schedule(tmp_path):
+    """The decoupled kernels test a leaf some node steps after they popped it, so the best_t a box is
+    culled against differs from launch to launch.  Certificate per ray (tests/cpu_sim
+    sim_schedule_certificate): the winner among ALL leaves the ray reaches without culling survives
+    the box tests of its own path against its own parameter, the smallest best_t any schedule can
+    hold.  Far from small spheres that needs the slack of Trav::cull_t and the own-box rule for
+    sphere hits: without the slack the same rays are at risk by the thousand."""
+    import subprocess
+    arrays, _, _ = load_scene("bouncing_spheres")
+    sim = S.SimScene(arrays)
+    for reach, seed in ((60, 3), (400, 4)):
+        risky, risky_without_slack, differs, leaves = sim.schedule_certificate(_rays_through_a_sphere_field(100_000, seed, reach))
+        assert risky == 0 and differs == 0, (reach, risky, differs)
+    assert risky_without_slack > 0  # (400 units away the rounding of sphere.h:47-52 reaches the radius)
+    # the synthetic grid scene at the distances of its 4K camera: camera rays, and rays leaving the hit points
+    rt_scenes = os.path.join(ROOT, "examples", "bin", "rt_scenes")
+    out = str(tmp_path / "synth.rtscene")
+    subprocess.run([rt_scenes, "synth1m", "--half", "150", "--dump", out], check=True, capture_output=True)
+    arrays, cam = abi.SceneArrays.load(out), abi.load_camera_file(out + ".cam")[0]
+    sim = S.SimScene(arrays)
+    f = binding.camera_initialize(cam)
+    rng = np.random.default_rng(8)
+    n = 150_000
+    px, py = rng.integers(0, f.image_width, n), rng.integers(0, f.image_height, n)
+    tgt = (np.array(f.pixel00_loc, np.float32) + px[:, None].astype(np.float32) * np.array(f.pixel_delta_u, np.float32)
+           + py[:, None].astype(np.float32) * np.array(f.pixel_delta_v, np.float32))
+    rays = np.zeros(n, abi.RAY_DT)
+    rays["orig"] = np.array(f.center, np.float32)
+    rays["dir"] = tgt - rays["orig"]
+    risky, risky_without_slack, differs, _ = sim.schedule_certificate(rays)
+    assert risky == 0 and differs == 0 and risky_without_slack > 100, (risky, risky_without_slack, differs)
+    hits, _, _ = sim.trace(rays)
+    m = hits["prim"] >= 0
+    d = rng.normal(size=(int(m.sum()), 3)).astype(np.float32)
+    d[:, 1] = np.abs(d[:, 1]) * 0.2
+    second = np.zeros(int(m.sum()), abi.RAY_DT)
+    second["orig"], second["dir"] = hits["p"][m], d
+    risky, _, differs, _ = sim.schedule_certificate(second)
+    assert risky == 0 and differs == 0, (risky, differs)
+
+
 def instanced_scene(n=96, seed=11):
     """Spheres (some moving) and quads inside translate / rotate_y / rotate_xyz / non-uniform
     scaling wrappers, enough of them for a BVH: the case the reference handles with
