@@ -59,6 +59,49 @@ RT_HD f3 cross(f3 a, f3 b) {
 RT_HD f3 unit(f3 v) { return v / len(v); }
 RT_HD f3 xyz(f4 v) { return mk(v.x, v.y, v.z); }
 
+// Shading arithmetic.  What happens to a path after its closest hit is known (the hit point and
+// normal of the winner, scatter directions, textures, camera rays) decides no hit, miss or
+// closest primitive, and the sampler's stream differs from the reference's anyway, so only its
+// distribution matters.  On the device that code fuses multiply-adds and uses the hardware's
+// 1-ulp reciprocal, square root and reciprocal square root (a correctly rounded sqrtf is 17
+// instructions, a correctly rounded division 10, many of them quarter rate).  Host builds keep the
+// plain operations, in the same order.  Off by default (-DRT_FAST_SHADE=1 turns it on): the kernel
+// gains 3 %, and paths through glass and mirrors, which otherwise follow the CPU restatement bit for
+// bit, then differ from it in the last bits of their directions, which a high-frequency texture far
+// away turns into visibly different texels (same distribution, different pixels).
+#ifndef RT_FAST_SHADE
+#define RT_FAST_SHADE 0
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && RT_FAST_SHADE
+#define RT_SHADE_FUSED 1
+#else
+#define RT_SHADE_FUSED 0
+#endif
+RT_HD float sh_fma(float a, float b, float c) { // a * b + c
+#if RT_SHADE_FUSED
+    return __builtin_fmaf(a, b, c);
+#else
+    return a * b + c;
+#endif
+}
+RT_HD float sh_sqrt(float x) {
+#if RT_SHADE_FUSED
+    return __builtin_amdgcn_sqrtf(x);
+#else
+    return sqrtf(x);
+#endif
+}
+RT_HD float sh_dot(f3 a, f3 b) { return sh_fma(a.z, b.z, sh_fma(a.y, b.y, a.x * b.x)); }
+RT_HD f3 sh_madd(float t, f3 v, f3 w) { return mk(sh_fma(t, v.x, w.x), sh_fma(t, v.y, w.y), sh_fma(t, v.z, w.z)); } // t * v + w
+RT_HD f3 sh_madd3(f3 a, f3 v, f3 w) { return mk(sh_fma(a.x, v.x, w.x), sh_fma(a.y, v.y, w.y), sh_fma(a.z, v.z, w.z)); }
+RT_HD f3 sh_unit(f3 v) { // vec3.h:124-126
+#if RT_SHADE_FUSED
+    return __builtin_amdgcn_rsqf(sh_dot(v, v)) * v;
+#else
+    return v / len(v);
+#endif
+}
+
 // Device code can be compiled without the quad, Perlin-noise, image-texture and instance-wrapper
 // branches (RT_LEAN: the "lean" render kernels for scenes that have none of them; fewer registers and
 // a shorter shading phase).  Host code always has every feature.
@@ -291,12 +334,12 @@ RT_HD f3 sample_unit_vector(Rng &rng) {
     float z = 1.0f - 2.0f * rng_next(rng);
     float s, c;
     sincos_2pi(rng_next(rng), s, c);
-    float rr = sqrtf(fmaxf(0.0f, 1.0f - z * z));
+    float rr = sh_sqrt(fmaxf(0.0f, 1.0f - z * z));
     return mk(rr * c, rr * s, z);
 }
 // Uniform point in the unit disk (vec3.h:130-136 uses rejection).
 RT_HD void sample_unit_disk(Rng &rng, float &px, float &py) {
-    float r = sqrtf(rng_next(rng));
+    float r = sh_sqrt(rng_next(rng));
     float s, c;
     sincos_2pi(rng_next(rng), s, c);
     px = r * c;
@@ -327,7 +370,8 @@ RT_HD bool sphere_test(f4 g0, f4 g1, f3 o, f3 d, float a, float tm, float tmin, 
 }
 
 // True if the point of the ray closest to the sphere's centre lies inside the sphere's own box
-// (centre +- radius, grown by a margin that is well inside the padding of the tree's boxes).  Far
+// (centre +- 1.019 radius + 9e-6 of the largest coordinate: inside the tree's box for the sphere,
+// which the host grows by at least 2 % of the radius + 1e-5 of the largest coordinate).  Far
 // from a small sphere the discriminant of sphere.h:47-52 is dominated by rounding, and a ray that
 // passes the sphere at more than its radius can still be reported as hitting it, at about the
 // parameter of its closest approach.  When that ray only clips a corner of the sphere's box, the
@@ -339,11 +383,12 @@ RT_HD bool sphere_test(f4 g0, f4 g1, f3 o, f3 d, float a, float tm, float tmin, 
 RT_HD bool sphere_approach_in_box(f4 g0, f4 g1, f3 o, f3 d, float a, float tm) {
     f3 center = xyz(g0) + tm * xyz(g1);
     f3 oc = center - o;
-    float tc = dot(d, oc) / a;
-    f3 cp = tc * d - oc;
+    float h = dot(d, oc);
+    // the closest point is o + (h / a) d; its offset from the centre, times a = |d|^2 > 0 (no division)
+    f3 off = h * d - a * oc;
     float m = fmaxf(fmaxf(fabsf(center.x), fabsf(center.y)), fabsf(center.z));
-    float half = __builtin_fmaf(m, 7e-6f, fabsf(g0.w) * 1.003f);
-    return fabsf(cp.x) <= half && fabsf(cp.y) <= half && fabsf(cp.z) <= half;
+    float half = a * __builtin_fmaf(m, 9e-6f, fabsf(g0.w) * 1.019f);
+    return fabsf(off.x) <= half && fabsf(off.y) <= half && fabsf(off.z) <= half;
 }
 
 // quad::hit + is_interior (quad.h:38-69, 80-91).  The interval is closed.
@@ -1098,7 +1143,9 @@ RT_HD void sphere_uv(f3 p, float &u, float &v) { // sphere.h:96-113
     v = theta / RT_PI;
 }
 
-RT_HD Surf surface_at(const DevScene &sc, const SceneView &vw, const Ray &r, TraceHit h) {
+// EXACT: the reference's operations one by one (the hit records of the batch queries, which are
+// compared with the reference's bit for bit); otherwise shading arithmetic (see sh_fma).
+template <bool EXACT = true> RT_HD Surf surface_at(const DevScene &sc, const SceneView &vw, const Ray &r, TraceHit h) {
     Surf s;
     i4 m = vw.rec_i[h.slot];
     s.rec = m;
@@ -1108,13 +1155,13 @@ RT_HD Surf surface_at(const DevScene &sc, const SceneView &vw, const Ray &r, Tra
     if (RT_FEAT_INSTANCE && inst_chain >= 0) chain_ray_to_object(sc, inst_chain, o, d);
     if (RT_FEAT_CHAIN && m.z >= 0) chain_ray_to_object(sc, m.z, o, d);
     const f4 *g = vw.slots + slot_words(sc, h.slot);
-    f3 p = o + h.t * d; // ray.h:20
+    f3 p = EXACT ? o + h.t * d : sh_madd(h.t, d, o); // ray.h:20
     f3 outward;
     s.u = 0.0f;
     s.v = 0.0f;
     if (!RT_FEAT_QUAD || RT_KIND_PRIM(m.x) == RT_PRIM_SPHERE) {
         f4 g0 = g[0], g1 = g[1];
-        f3 center = xyz(g0) + r.tm * xyz(g1);
+        f3 center = EXACT ? xyz(g0) + r.tm * xyz(g1) : sh_madd(r.tm, xyz(g1), xyz(g0));
         outward = g1.w * (p - center); // sphere.h:68 (g1.w = 1 / radius)
     } else {
         f4 g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
@@ -1127,7 +1174,7 @@ RT_HD Surf surface_at(const DevScene &sc, const SceneView &vw, const Ray &r, Tra
         s.v = dot(w, cross(u, planar));
     }
     s.outward = outward;
-    s.front = dot(d, outward) < 0; // hittable.h:20-25
+    s.front = (EXACT ? dot(d, outward) : sh_dot(d, outward)) < 0; // hittable.h:20-25
     f3 n = s.front ? outward : -outward;
     if (RT_FEAT_CHAIN && m.z >= 0) chain_hit_to_world(sc, m.z, p, n);
     if (RT_FEAT_INSTANCE && inst_chain >= 0) chain_hit_to_world(sc, inst_chain, p, n);
@@ -1142,9 +1189,9 @@ RT_HD float perlin_noise(const DevPerlin &pn, f3 p) {
     float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
     float u = p.x - fx, v = p.y - fy, w = p.z - fz;
     int i = int(fx), j = int(fy), k = int(fz);
-    float uu = u * u * (3 - 2 * u);
-    float vv = v * v * (3 - 2 * v);
-    float ww = w * w * (3 - 2 * w);
+    float uu = u * u * sh_fma(-2.0f, u, 3.0f);
+    float vv = v * v * sh_fma(-2.0f, v, 3.0f);
+    float ww = w * w * sh_fma(-2.0f, w, 3.0f);
     // the reference hashes all three axes through perm_x (perlin.h:33)
     int pi0 = pn.perm_x[i & 255], pi1 = pn.perm_x[(i + 1) & 255];
     int pj0 = pn.perm_x[j & 255], pj1 = pn.perm_x[(j + 1) & 255];
@@ -1163,7 +1210,7 @@ RT_HD float perlin_noise(const DevPerlin &pn, f3 p) {
                 // of the two products is 0 * x = 0 and the other 1 * y = y (uu, vv, ww lie in [0, 1]),
                 // and y + 0 = y, so each factor is uu or 1 - uu bit for bit; the compiler may not fold
                 // that itself (0 * x is not 0 for every x), so it is written out
-                accum += (di ? uu : 1 - uu) * (dj ? vv : 1 - vv) * (dk ? ww : 1 - ww) * dot(c, wv);
+                accum = sh_fma((di ? uu : 1 - uu) * (dj ? vv : 1 - vv) * (dk ? ww : 1 - ww), sh_dot(c, wv), accum);
             }
     return accum;
 }
@@ -1171,7 +1218,7 @@ RT_HD float perlin_turb(const DevPerlin &pn, f3 p, int depth) {
     float accum = 0.0f;
     float weight = 1.0f;
     for (int i = 0; i < depth; i++) {
-        accum += weight * perlin_noise(pn, p);
+        accum = sh_fma(weight, perlin_noise(pn, p), accum);
         weight *= 0.5f;
         p = mk(p.x * 2, p.y * 2, p.z * 2);
     }
@@ -1196,7 +1243,7 @@ RT_HD f3 texture_value(const DevScene &sc, const SceneView &vw, int tex, const S
     if (t.type == RT_TEX_SOLID) return mk(t.color[0], t.color[1], t.color[2]);
     if (RT_FEAT_NOISE && t.type == RT_TEX_NOISE) { // texture.h:85-90
         RT_COUNT(noise);
-        float ph = t.scale * s.p.z + 10.0f * perlin_turb(vw.perlins[t.perlin], s.p, 7);
+        float ph = sh_fma(10.0f, perlin_turb(vw.perlins[t.perlin], s.p, 7), t.scale * s.p.z);
         return mk(0.5f, 0.5f, 0.5f) * (1.0f + sinf(ph));
     }
     if (RT_FEAT_IMAGE && t.type == RT_TEX_IMAGE) { // texture.h:60-74, rtw_stb_image.h:69-94
@@ -1228,7 +1275,7 @@ RT_HD Ray camera_ray(const DevCamera &cam, int i, int j, Rng &rng) {
     f3 p00 = mk(f.pixel00_loc[0], f.pixel00_loc[1], f.pixel00_loc[2]);
     f3 du = mk(f.pixel_delta_u[0], f.pixel_delta_u[1], f.pixel_delta_u[2]);
     f3 dv = mk(f.pixel_delta_v[0], f.pixel_delta_v[1], f.pixel_delta_v[2]);
-    f3 pixel_sample = p00 + ((i + dx) * du) + ((j + dy) * dv);
+    f3 pixel_sample = sh_madd(j + dy, dv, sh_madd(i + dx, du, p00));
     f3 center = mk(f.center[0], f.center[1], f.center[2]);
     f3 origin = center;
     if (!(cam.defocus_angle <= 0)) {
@@ -1236,7 +1283,7 @@ RT_HD Ray camera_ray(const DevCamera &cam, int i, int j, Rng &rng) {
         sample_unit_disk(rng, px, py);
         f3 ddu = mk(f.defocus_disk_u[0], f.defocus_disk_u[1], f.defocus_disk_u[2]);
         f3 ddv = mk(f.defocus_disk_v[0], f.defocus_disk_v[1], f.defocus_disk_v[2]);
-        origin = center + (px * ddu) + (py * ddv);
+        origin = sh_madd(py, ddv, sh_madd(px, ddu, center));
     }
     Ray r;
     r.o = origin;
@@ -1256,17 +1303,16 @@ struct PathState {
     int depth; // bounces left
 };
 
-RT_HD f3 reflect(f3 v, f3 n) { return v - 2.0f * dot(v, n) * n; } // vec3.h:163
-RT_HD f3 refract(f3 uv, f3 n, float etai_over_etat) {             // vec3.h:169
-    float cos_theta = fminf(dot(-uv, n), 1.0f);
-    f3 r_out_perp = etai_over_etat * (uv + cos_theta * n);
-    f3 r_out_parallel = -sqrtf(fabsf(1.0f - len2(r_out_perp))) * n;
-    return r_out_perp + r_out_parallel;
+RT_HD f3 reflect(f3 v, f3 n) { return sh_madd(-(2.0f * sh_dot(v, n)), n, v); } // vec3.h:163
+RT_HD f3 refract(f3 uv, f3 n, float etai_over_etat) {                          // vec3.h:169
+    float cos_theta = fminf(sh_dot(-uv, n), 1.0f);
+    f3 r_out_perp = etai_over_etat * sh_madd(cos_theta, n, uv);
+    return sh_madd(-sh_sqrt(fabsf(1.0f - sh_dot(r_out_perp, r_out_perp))), n, r_out_perp);
 }
 RT_HD float schlick_r0(float cosine, float r0) { // material.h:101-102, r0 given
     float x = 1.0f - cosine;
     float x2 = x * x;
-    return r0 + (1.0f - r0) * (x2 * x2 * x);
+    return sh_fma(1.0f - r0, x2 * x2 * x, r0);
 }
 RT_HD float schlick(float cosine, float ri) { // material.h:97-103
     float r0 = (1.0f - ri) / (1.0f + ri);
@@ -1287,7 +1333,7 @@ RT_HD bool shade_hit(const DevScene &sc, const SceneView &vw, int slot, PathStat
         col = texture_value<COUNT>(sc, vw, s.rec.y, s, cn);
     if (mat == RT_MAT_DIFFUSE_LIGHT) { // material.h:113-115: emits on both faces, never scatters
         RT_COUNT(sh3);
-        ps.L = ps.L + ps.beta * col;
+        ps.L = sh_madd3(ps.beta, col, ps.L);
         return false;
     }
     // The three scattering materials share what is expensive in them: every one draws a first
@@ -1303,11 +1349,11 @@ RT_HD bool shade_hit(const DevScene &sc, const SceneView &vw, int slot, PathStat
     f3 vu = mk(0.0f, 0.0f, 0.0f);
     if (RT_WAVE_ANY(!lamb)) { // (scenes of lambertian surfaces only skip this as a wave)
         const f3 reflected = reflect(ps.ray.d, s.n);
-        vu = unit(diel ? ps.ray.d : reflected);
+        vu = sh_unit(diel ? ps.ray.d : reflected);
     }
-    const float cos_theta = fminf(dot(-vu, s.n), 1.0f);
-    const float z = 1.0f - 2.0f * u1;
-    const float root = sqrtf(diel ? 1.0f - cos_theta * cos_theta : fmaxf(0.0f, 1.0f - z * z));
+    const float cos_theta = fminf(sh_dot(-vu, s.n), 1.0f);
+    const float z = sh_fma(-2.0f, u1, 1.0f);
+    const float root = sh_sqrt(diel ? sh_fma(-cos_theta, cos_theta, 1.0f) : fmaxf(0.0f, sh_fma(-z, z, 1.0f)));
     f3 dir;
     if (diel) { // material.h:72-90
         RT_COUNT(sh2);
@@ -1335,8 +1381,8 @@ RT_HD bool shade_hit(const DevScene &sc, const SceneView &vw, int slot, PathStat
             if (fabsf(dir.x) < 1e-8f && fabsf(dir.y) < 1e-8f && fabsf(dir.z) < 1e-8f) dir = s.n;
         } else {
             RT_COUNT(sh1);
-            dir = vu + (rf.w * rv);
-            if (!(dot(dir, s.n) > 0)) return false; // absorbed: contributes nothing
+            dir = sh_madd(rf.w, rv, vu);
+            if (!(sh_dot(dir, s.n) > 0)) return false; // absorbed: contributes nothing
         }
     }
     ps.beta = ps.beta * col;
@@ -1363,10 +1409,10 @@ template <bool COUNT>
 RT_HD bool path_after_trace(const DevScene &sc, const SceneView &vw, const DevCamera &cam, PathState &ps,
                             TraceHit h, Cnt<COUNT> &cn) {
     if (h.slot < 0) {
-        ps.L = ps.L + ps.beta * mk(cam.background[0], cam.background[1], cam.background[2]);
+        ps.L = sh_madd3(ps.beta, mk(cam.background[0], cam.background[1], cam.background[2]), ps.L);
         return false;
     }
-    Surf s = surface_at(sc, vw, ps.ray, h);
+    Surf s = surface_at<false>(sc, vw, ps.ray, h);
     ps.depth--;
     return shade_hit<COUNT>(sc, vw, h.slot, ps, s, cn) && ps.depth > 0; // depth 0: camera.h:141 returns black
 }

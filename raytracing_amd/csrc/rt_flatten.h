@@ -169,11 +169,16 @@ struct Box3 {
 // the ideal primitive by a hair (a sphere seen from distance L can be off by about
 // 2e-7 L^2 / r).  Culling must never drop such a hit, so boxes are grown by a small
 // fraction of their size plus a few ulps of their coordinates.
-void pad_box(Box3 &b) {
+// rel: the fraction of the box's largest extent.  A sphere's box is grown by RT_SPHERE_PAD_REL of it
+// (at least 2 % of the radius): the tree walk keeps a sphere's hit only if the ray's closest
+// approach to the centre lies within 1.9 % of the radius of the sphere's own box
+// (rt_core.h sphere_approach_in_box), and that smaller box must lie inside this one.
+#define RT_SPHERE_PAD_REL 1e-2f
+void pad_box(Box3 &b, float rel = 2e-3f) {
     float ext = std::max(b.hi[0] - b.lo[0], std::max(b.hi[1] - b.lo[1], b.hi[2] - b.lo[2]));
     float mag = 0.0f;
     for (int k = 0; k < 3; k++) mag = std::max(mag, std::max(std::fabs(b.lo[k]), std::fabs(b.hi[k])));
-    float pad = 2e-3f * ext + 1e-5f * mag + 1e-30f;
+    float pad = rel * ext + 1e-5f * mag + 1e-30f;
     for (int k = 0; k < 3; k++) {
         b.lo[k] -= pad;
         b.hi[k] += pad;
@@ -810,7 +815,7 @@ inline int flatten_scene(const rt_scene_desc *d, uint32_t flags, HostScene &out,
                         b.add(to_world(mk((corner & 1) ? ob.hi[0] : ob.lo[0], (corner & 2) ? ob.hi[1] : ob.lo[1],
                                           (corner & 4) ? ob.hi[2] : ob.lo[2])));
                 }
-                pad_box(b);
+                pad_box(b, RT_SPHERE_PAD_REL);
             }
         } else {
             f3 Q = mk(p.a[0], p.a[1], p.a[2]), u = mk(p.b[0], p.b[1], p.b[2]), v = mk(p.c[0], p.c[1], p.c[2]);

@@ -8,15 +8,19 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
 step() { echo "== $*" | tee -a $O/session.log; }
+if [ -z "$SKIP_TESTS" ]; then
 step tests
 timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 180 --timeout-method thread > $O/tests.log 2>&1 || { tail -n 30 $O/tests.log; exit 1; }
 tail -n 3 $O/tests.log
+fi
+if [ -z "$SKIP_SOAK" ]; then
 step soak synth1m
 timeout -k 10 400 python -u tools/soak.py synth1m 4 ${SOAK_SYNTH:-800} > $O/soak_synth1m.log 2>&1 || { tail -n 5 $O/soak_synth1m.log; exit 1; }
 tail -n 2 $O/soak_synth1m.log
 step soak bouncing_spheres
 timeout -k 10 300 python -u tools/soak.py bouncing_spheres 100 ${SOAK_BOUNCING:-4000} > $O/soak_bouncing.log 2>&1 || { tail -n 5 $O/soak_bouncing.log; exit 1; }
 tail -n 2 $O/soak_bouncing.log
+fi
 if [ $# -gt 0 ]; then
   step ab bouncing
   timeout -k 10 600 tools/ab.sh -r 3 "$@" 2>&1 | tee $O/ab_bouncing.log || exit 1
