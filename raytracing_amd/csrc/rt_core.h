@@ -370,8 +370,8 @@ RT_HD bool sphere_test(f4 g0, f4 g1, f3 o, f3 d, float a, float tm, float tmin, 
 }
 
 // True if the point of the ray closest to the sphere's centre lies inside the sphere's own box
-// (centre +- 1.019 radius + 9e-6 of the largest coordinate: inside the tree's box for the sphere,
-// which the host grows by at least 2 % of the radius + 1e-5 of the largest coordinate).  Far
+// (centre +- 1.019 radius: inside the tree's box for the sphere, which the host grows by at least
+// 2 % of the radius).  Far
 // from a small sphere the discriminant of sphere.h:47-52 is dominated by rounding, and a ray that
 // passes the sphere at more than its radius can still be reported as hitting it, at about the
 // parameter of its closest approach.  When that ray only clips a corner of the sphere's box, the
@@ -383,11 +383,16 @@ RT_HD bool sphere_test(f4 g0, f4 g1, f3 o, f3 d, float a, float tm, float tmin, 
 RT_HD bool sphere_approach_in_box(f4 g0, f4 g1, f3 o, f3 d, float a, float tm) {
     f3 center = xyz(g0) + tm * xyz(g1);
     f3 oc = center - o;
+    // Nearer than 160 radii no such hit exists: the computed discriminant is off by less than
+    // 24 * 2^-24 |d|^2 |oc|^2 (19 roundings of terms of that size at most), and a closest approach
+    // outside the box below means a true discriminant below -0.038 |d|^2 radius^2.
+    float r2 = g0.w * g0.w;
+    float c = len2(oc) - r2;
+    if (!(c > 26000.0f * r2)) return true; // (most waves skip the rest)
     float h = dot(d, oc);
     // the closest point is o + (h / a) d; its offset from the centre, times a = |d|^2 > 0 (no division)
     f3 off = h * d - a * oc;
-    float m = fmaxf(fmaxf(fabsf(center.x), fabsf(center.y)), fabsf(center.z));
-    float half = a * __builtin_fmaf(m, 9e-6f, fabsf(g0.w) * 1.019f);
+    float half = (a * 1.019f) * fabsf(g0.w);
     return fabsf(off.x) <= half && fabsf(off.y) <= half && fabsf(off.z) <= half;
 }
 
@@ -773,7 +778,12 @@ template <typename T, int STRIDE = 0> struct TravStack {
 // sqrt(k eps) |oc| / |d| near a silhouette (k: a handful of roundings of terms of size |oc|^2 |d|^2 in
 // the discriminant; eps = 2^-24: about 1e-3 of the distance), so a primitive's reported hit can lie
 // that far in front of its own box.
+#ifndef RT_CULL_REL
 #define RT_CULL_REL 1.953125e-3f
+#endif
+#ifndef RT_OWN_BOX_RULE
+#define RT_OWN_BOX_RULE 1 // (0: what-if builds that measure the rule's cost)
+#endif
 struct Trav {
     BoxRay br;
     float best_t;
@@ -995,7 +1005,8 @@ RT_HD void trav_inner(Trav &tv, const f4 *nodes, float tmin, const ST &st, int r
     trav_pop<ST, SPILL>(tv, st, ref_bits);
 }
 // Exact test of one leaf against the current best (ties included).
-template <bool COUNT>
+// IN_TREE: the leaf was reached through the tree (false: one of the primitives tested up front).
+template <bool COUNT, bool IN_TREE = true>
 RT_HD void trav_test_leaf(Trav &tv, int leaf_ref, const DevScene &sc, const SceneView &v, const Ray &r,
                           float tmin, Cnt<COUNT> &cn) {
     int code = ~leaf_ref;
@@ -1032,7 +1043,7 @@ RT_HD void trav_test_leaf(Trav &tv, int leaf_ref, const DevScene &sc, const Scen
         if constexpr (COUNT) cn.sphh += h ? 1 : 0;
         h = h && t <= tv.best_t;
         // (primitives tested up front are never culled: their hits stand as computed)
-        if (h && s >= sc.n_big) h = sphere_approach_in_box(g[0], g[1], o, d, dd, r.tm);
+        if (RT_OWN_BOX_RULE && IN_TREE && h) h = sphere_approach_in_box(g[0], g[1], o, d, dd, r.tm);
     } else {
         RT_COUNT(quad);
         h = quad_test(g[0], g[1], g[2], g[3], o, d, tmin, tv.best_t, t);
@@ -1058,7 +1069,7 @@ RT_HD void trav_test_leaf(Trav &tv, int leaf_ref, const DevScene &sc, const Scen
 template <bool COUNT>
 RT_HD void trav_test_big(Trav &tv, const DevScene &sc, const SceneView &v, const Ray &r, float tmin, Cnt<COUNT> &cn) {
     for (int j = 0; j < sc.n_big; j++)
-        trav_test_leaf<COUNT>(tv, ~(j * 2 + ((sc.big_quads >> j) & 1)), sc, v, r, tmin, cn);
+        trav_test_leaf<COUNT, false>(tv, ~(j * 2 + ((sc.big_quads >> j) & 1)), sc, v, r, tmin, cn);
 }
 
 // Two-level scenes.  A leaf whose slot lies beyond the primitives is not a primitive: slot
