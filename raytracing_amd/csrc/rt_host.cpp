@@ -207,18 +207,14 @@ LaunchGeom choose_geom(rt_scene *s, uint32_t flags) {
         for (bpc = bpc_target; bpc >= 1 && !lg.lds_scene; bpc--) {
             size_t budget = lds_budget(bpc);
             size_t stack = (size_t)cap * RT_MEGA_MAX_THREADS * sizeof(short); // rows of the full workgroup size
+            // A scene held in LDS is held there whole, records and texture table included: the kernels
+            // then read them with LDS instructions (a pointer that may be either LDS or global memory
+            // makes every record access a flat load with 64-bit address arithmetic).  The rings yield
+            // first; a scene whose geometry alone would fit is read from HBM with the tree's top in LDS.
             if (all_bytes + stack <= budget) {
                 lg.lds_scene = true;
                 lg.lds_records = 1;
                 used = all_bytes + stack;
-                // the rings are worth more than the records in LDS (the records are read once per hit)
-                if (ring_bytes && used + ring_bytes > budget && geom_bytes + stack + ring_bytes <= budget) {
-                    lg.lds_records = 0;
-                    used = geom_bytes + stack;
-                }
-            } else if (geom_bytes + stack <= budget) {
-                lg.lds_scene = true;
-                used = geom_bytes + stack;
             }
             if (lg.lds_scene) {
                 lg.ring = ring_bytes && used + ring_bytes <= budget;

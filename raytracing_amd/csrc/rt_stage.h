@@ -31,18 +31,18 @@ __device__ __forceinline__ f4 *stage_scene(const DevScene &sc, f4 *smem, SceneVi
     stage_nodes_to_lds(p, sc.nodes, sc.n_nodes);
     v.nodes = p;
     p += n_node_words;
-    if (sc.lds_records) {
-        stage_to_lds(p, reinterpret_cast<const f4 *>(sc.rec_i), sc.n_slots);
-        v.rec_i = reinterpret_cast<const i4 *>(p);
-        p += sc.n_slots;
-        stage_to_lds(p, sc.rec_f, sc.n_slots);
-        v.rec_f = p;
-        p += sc.n_slots;
-        // the device copy of the texture table is padded to whole 16-byte words
-        stage_to_lds(p, reinterpret_cast<const f4 *>(sc.textures), n_tex_words);
-        v.textures = reinterpret_cast<const rt_texture *>(p);
-        p += n_tex_words;
-    }
+    // (unconditionally: the host only picks the LDS variants when all of this fits, and pointers that
+    // are LDS on every path let the compiler use LDS instructions for the records)
+    stage_to_lds(p, reinterpret_cast<const f4 *>(sc.rec_i), sc.n_slots);
+    v.rec_i = reinterpret_cast<const i4 *>(p);
+    p += sc.n_slots;
+    stage_to_lds(p, sc.rec_f, sc.n_slots);
+    v.rec_f = p;
+    p += sc.n_slots;
+    // the device copy of the texture table is padded to whole 16-byte words
+    stage_to_lds(p, reinterpret_cast<const f4 *>(sc.textures), n_tex_words);
+    v.textures = reinterpret_cast<const rt_texture *>(p);
+    p += n_tex_words;
     if (sc.lds_perlins) { // noise textures gather from these tables 50 times per evaluation
         const int n_perlin_words = sc.n_perlins * (int)(sizeof(DevPerlin) / sizeof(f4));
         stage_to_lds(p, reinterpret_cast<const f4 *>(sc.perlins), n_perlin_words);
