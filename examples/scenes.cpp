@@ -276,7 +276,8 @@ static void grove() {
 
 // 10^6 cells on a grid, one sphere or quad per cell, plus the ground: splitmix64 keyed layout,
 // twelve draws per cell whether they are used or not.
-static void synth1m(int half) {
+// under_bvh / width 480: the two reduced forms the reference harness records (synth60_list, synth60_bvh).
+static void synth1m(int half, bool under_bvh = false, int width = 3840) {
     uint64_t state = 0x5EED1234ull;
     auto u01 = [&]() {
         uint64_t z = (state += 0x9E3779B97F4A7C15ull);
@@ -304,8 +305,10 @@ static void synth1m(int half) {
                 world.add(make_shared<quad>(base, vec3(0.4f * (q0 - 0.5f), 0.0f, 0.4f * (q1 - 0.5f) + 0.2f),
                                             vec3(0.1f * (q2 - 0.5f), 2.0f * r, 0.0f), mat));
         }
-    // no bvh_node: the library builds its own tree over anything larger than a handful of primitives
-    shoot(world, View{kWide, 3840, 1, kSky, 40.0f, point3(0.0f, 40.0f, 130.0f), point3(0.0f, 0.0f, 0.0f), 0.0f, 10.0f});
+    // (the library builds its own tree over anything larger than a handful of primitives either way;
+    // under a bvh_node the primitives are numbered in the order of that tree's leaves, which decides ties)
+    if (under_bvh) world = hittable_list(make_shared<bvh_node>(world));
+    shoot(world, View{kWide, width, 1, kSky, 40.0f, point3(0.0f, 40.0f, 130.0f), point3(0.0f, 0.0f, 0.0f), 0.0f, 10.0f});
 }
 
 int main(int argc, char **argv) {
@@ -337,6 +340,8 @@ int main(int argc, char **argv) {
     else if (s == "rotated_in_bvh") rotated_in_bvh();
     else if (s == "grove") grove();
     else if (s == "synth1m") synth1m(synth_half);
+    else if (s == "synth60_list") synth1m(60, false, 480);
+    else if (s == "synth60_bvh") synth1m(60, true, 480);
     else {
         fprintf(stderr, "unknown scene %s\n", argv[1]);
         return 2;

@@ -28,9 +28,12 @@ SCENES = ["bouncing_spheres", "checkered_spheres", "earth", "perlin_spheres", "q
           "simple_light", "cornell_box"]
 # spp of the converged reference images (the PSNR >= 40 dB gate needs about this much)
 IMAGE_SPP = {"bouncing_spheres": 1024, "checkered_spheres": 1024, "earth": 1024,
-             "perlin_spheres": 1024, "quads": 1024, "simple_light": 8192, "cornell_box": 16384}
+             "perlin_spheres": 1024, "quads": 1024, "simple_light": 8192, "cornell_box": 16384,
+             "synth60_bvh": 1024}
 # scenes of the harness itself (not in main.cpp): scene dump, camera and ray records only
-EXTRA_SCENES = ["rotated_in_bvh"]
+# (synth60_*: the synthetic grid scene of the 4K configuration at 14 401 primitives, as a plain list and
+# under one bvh_node; `images synth60_bvh` also renders the latter's converged image)
+EXTRA_SCENES = ["rotated_in_bvh", "synth60_list", "synth60_bvh"]
 RAY_PATHS = 1500
 PIN_SPP = 2
 PIN_ROWS = 24

@@ -10,7 +10,8 @@
 //   bvhcheck <scene> <n_paths>                    bvh_node::hit vs linear scan of its leaves
 //   refpng   <scene> <out.png>                    the reference's own camera::render, untouched
 // Scene = bouncing_spheres | checkered_spheres | earth | perlin_spheres | quads |
-//         simple_light | cornell_box  (the seven functions of main.cpp:14-288).
+//         simple_light | cornell_box  (the seven functions of main.cpp:14-288), or one of the
+//         harness's own: rotated_in_bvh, synth60_list, synth60_bvh.
 //
 // Nothing from the reference is copied here: the file only calls into it.
 
@@ -94,6 +95,57 @@ static void rotated_in_bvh() {
     cam.vfov = 35.0f;
     cam.lookfrom = point3(6.0f, 4.0f, 9.0f);
     cam.lookat = point3(0.0f, 0.8f, 0.0f);
+    cam.vup = vec3(0.0f, 1.0f, 0.0f);
+    cam.defocus_angle = 0.0f;
+    harness_capture(cam, world);
+}
+
+// The synthetic grid scene of the 4K configuration (one sphere or quad per cell of a
+// [-half, half)^2 grid + a ground sphere; the layout is keyed by splitmix64, twelve draws per cell
+// in a fixed order, so it does not depend on the compiler's argument evaluation order), built from
+// the reference's own classes: as a plain hittable_list (hittable_list.h:29-43 scans every
+// primitive) and under one bvh_node (bvh.h:48-88).  The reference has no such scene; these two
+// give its answers for it.  Camera: the 4K view at 480 x 270.
+static void synth_grid(int half, bool under_bvh) {
+    uint64_t state = 0x5EED1234ull;
+    auto u01 = [&]() {
+        uint64_t z = (state += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        return float(z >> 40) * (1.0f / 16777216.0f);
+    };
+    hittable_list world;
+    auto checker = make_shared<checker_texture>(0.32f, color(0.2f, 0.3f, 0.1f), color(0.9f, 0.9f, 0.9f));
+    world.add(make_shared<sphere>(point3(0.0f, -10000.0f, 0.0f), 10000.0f, make_shared<lambertian>(checker)));
+    for (int a = -half; a < half; a++)
+        for (int b = -half; b < half; b++) {
+            float kind = u01(), choose = u01(), jx = u01(), jz = u01(), rr = u01();
+            float c0 = u01(), c1 = u01(), c2 = u01(), f = u01(), q0 = u01(), q1 = u01(), q2 = u01();
+            float r = 0.1f + 0.15f * rr;
+            point3 base(a + 0.9f * jx, 0.0f, b + 0.9f * jz);
+            shared_ptr<material> mat;
+            if (choose < 0.8f) mat = make_shared<lambertian>(color(c0 * c0, c1 * c1, c2 * c2));
+            else if (choose < 0.95f) mat = make_shared<metal>(color(0.5f + 0.5f * c0, 0.5f + 0.5f * c1, 0.5f + 0.5f * c2), 0.5f * f);
+            else if (choose < 0.99f) mat = make_shared<dielectric>(1.5f);
+            else mat = make_shared<diffuse_light>(color(4.0f * c0, 4.0f * c1, 4.0f * c2));
+            if (kind < 0.75f)
+                world.add(make_shared<sphere>(base + vec3(0.0f, r, 0.0f), r, mat));
+            else
+                world.add(make_shared<quad>(base, vec3(0.4f * (q0 - 0.5f), 0.0f, 0.4f * (q1 - 0.5f) + 0.2f),
+                                            vec3(0.1f * (q2 - 0.5f), 2.0f * r, 0.0f), mat));
+        }
+    if (under_bvh) world = hittable_list(make_shared<bvh_node>(world));
+
+    camera cam;
+    cam.aspect_ratio = 16.0f / 9.0f;
+    cam.image_width = 480;
+    cam.samples_per_pixel = 1;
+    cam.max_depth = 50;
+    cam.background = color(0.70f, 0.80f, 1.00f);
+    cam.vfov = 40.0f;
+    cam.lookfrom = point3(0.0f, 40.0f, 130.0f);
+    cam.lookat = point3(0.0f, 0.0f, 0.0f);
     cam.vup = vec3(0.0f, 1.0f, 0.0f);
     cam.defocus_angle = 0.0f;
     harness_capture(cam, world);
@@ -711,6 +763,8 @@ int main(int argc, char **argv) {
     else if (s == "simple_light") simple_light();
     else if (s == "cornell_box") cornell_box();
     else if (s == "rotated_in_bvh") rotated_in_bvh();
+    else if (s == "synth60_list") synth_grid(60, false);
+    else if (s == "synth60_bvh") synth_grid(60, true);
     else {
         fprintf(stderr, "harness: unknown scene %s\n", s.c_str());
         return 2;

@@ -134,11 +134,23 @@ class Scene:
         return i
 
     def nodes(self):
-        """The nodes of the 4-wide BVH as an (n_nodes, 32) float32 array (child k's box: [:, 6k:6k+6] =
-        centre, half extent; the references and the child count are the bit patterns of [:, 24:29])."""
+        """The nodes of the 4-wide BVH as an (n_nodes, 32) float32 array in the kernels' plane layout:
+        words 8a + k and 8a + 4 + k are the lower and the upper plane of child k's box along axis a
+        (a = 0, 1, 2); the four child references and the child count are the bit patterns of
+        [:, 24:29].  node_boxes() decodes the planes."""
         out = np.zeros((self.info().n_nodes, 32), np.float32)
         check(lib().rt_scene_read_nodes(self.handle, out.ctypes.data, out.nbytes))
         return out
+
+    def node_boxes(self):
+        """(lo, hi, refs, n_children): lo / hi are (n_nodes, 4, 3) arrays with the corners of the four
+        child boxes of every node (an unused child has an inverted box), refs (n_nodes, 4) int32."""
+        n = self.nodes()
+        planes = n[:, :24].reshape(-1, 3, 2, 4)  # [node, axis, lo | hi, child]
+        lo = np.ascontiguousarray(planes[:, :, 0, :].transpose(0, 2, 1))
+        hi = np.ascontiguousarray(planes[:, :, 1, :].transpose(0, 2, 1))
+        ints = n.view(np.int32)
+        return lo, hi, ints[:, 24:28].copy(), ints[:, 28].copy()
 
     def trace(self, rays, tmin=0.001, tmax=np.inf, sched=False):
         """Closest hits of a ray batch; sched=True: through the render kernel's own traversal."""

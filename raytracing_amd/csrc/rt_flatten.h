@@ -919,14 +919,31 @@ inline int flatten_scene(const rt_scene_desc *d, uint32_t flags, HostScene &out,
                 max_sub_levels = std::max(max_sub_levels, sub.wide.levels);
             }
         }
-        // loose primitives whose box takes up most of the world's are tested up front (as in the
-        // one-level case below) and become the first slots
+        // the instances' boxes in the world: the sub-scene's box pushed through the instance's wrappers
+        std::vector<Box3> inst_boxes(d->n_instances);
+        for (int k = 0; k < d->n_instances; k++) {
+            const Sub &sub = subs[inst_template[k]];
+            Box3 &b = inst_boxes[k];
+            b.reset();
+            const int c = d->instances[k].xform;
+            const int first = c >= 0 ? d->chains[c].first_op : 0, last = c >= 0 ? first + d->chains[c].n_ops : 0;
+            for (int corner = 0; corner < 8; corner++) {
+                f3 q = mk((corner & 1) ? sub.box.hi[0] : sub.box.lo[0], (corner & 2) ? sub.box.hi[1] : sub.box.lo[1],
+                          (corner & 4) ? sub.box.hi[2] : sub.box.lo[2]);
+                for (int o = first; o < last; o++) q = op_point(ops[o], q);
+                b.add(q);
+            }
+            pad_box(b);
+        }
+        // loose primitives whose box takes up most of the world's (loose primitives and instances
+        // together) are tested up front (as in the one-level case below) and become the first slots
         std::vector<int> big;
         {
             Box3 all;
             all.reset();
             for (int i = 0; i < n; i++)
                 if (!in_template[i]) all.add(boxes[i]);
+            for (const Box3 &b : inst_boxes) all.add(b);
             const float limit = kBigPrimArea * all.area();
             for (int i = 0; i < n; i++)
                 if (!in_template[i] && (int)big.size() < kBigPrimMax && boxes[i].area() >= limit) big.push_back(i);
@@ -946,19 +963,7 @@ inline int flatten_scene(const rt_scene_desc *d, uint32_t flags, HostScene &out,
             }
         const int n_loose = (int)item_prim.size();
         for (int k = 0; k < d->n_instances; k++) {
-            const Sub &sub = subs[inst_template[k]];
-            Box3 b;
-            b.reset();
-            const int c = d->instances[k].xform;
-            const int first = c >= 0 ? d->chains[c].first_op : 0, last = c >= 0 ? first + d->chains[c].n_ops : 0;
-            for (int corner = 0; corner < 8; corner++) {
-                f3 q = mk((corner & 1) ? sub.box.hi[0] : sub.box.lo[0], (corner & 2) ? sub.box.hi[1] : sub.box.lo[1],
-                          (corner & 4) ? sub.box.hi[2] : sub.box.lo[2]);
-                for (int o = first; o < last; o++) q = op_point(ops[o], q);
-                b.add(q);
-            }
-            pad_box(b);
-            ib.push_back(b);
+            ib.push_back(inst_boxes[k]);
             it.push_back(RT_PRIM_SPHERE);
         }
         const int n_items = (int)ib.size();

@@ -284,8 +284,17 @@ const char *rt_last_error(void) { return g_err.c_str(); }
 // overlap (measured: 7.4 instead of 8.3 Gpaths/s with RCCL initialised).  Eight queues are enough.
 // This only helps if the library is loaded before the HIP runtime reads its settings (a C++
 // program linked against it; Python harnesses set the variable themselves before importing torch),
-// and never overrides a value the user has set.
-__attribute__((constructor)) static void rt_amd_more_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+// and never overrides a value the user has set.  RT_AMD_KEEP_HW_QUEUES=1 leaves the environment
+// alone; RT_AMD_DEBUG=1 says on stderr when the variable was set here.
+__attribute__((constructor)) static void rt_amd_more_hw_queues() {
+    const char *keep = getenv("RT_AMD_KEEP_HW_QUEUES");
+    if (keep && atoi(keep) != 0) return;
+    if (getenv("GPU_MAX_HW_QUEUES")) return;
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    const char *dbg = getenv("RT_AMD_DEBUG");
+    if (dbg && atoi(dbg) != 0)
+        fprintf(stderr, "librt_amd: set GPU_MAX_HW_QUEUES=8 for this process (RT_AMD_KEEP_HW_QUEUES=1 prevents it)\n");
+}
 
 int rt_abi_version(void) { return RT_AMD_ABI_VERSION; }
 

@@ -13,7 +13,9 @@ SCENES = ["bouncing_spheres", "checkered_spheres", "earth", "perlin_spheres", "q
 # Scenes of the reference harness itself (not in the reference's main.cpp), with a scene dump, a camera
 # and ray records only.  rotated_in_bvh: rotated objects inside a bvh_node, which the reference clips
 # to the too-small boxes of its rotate_y / rotate_xyz constructors (hittable.h:123-126, 241-244).
-EXTRA_SCENES = ["rotated_in_bvh"]
+# synth60_list / synth60_bvh: the synthetic grid scene of the 4K configuration at 14 401 primitives, built
+# from the reference's classes as a plain hittable_list and under one bvh_node.
+EXTRA_SCENES = ["rotated_in_bvh", "synth60_list", "synth60_bvh"]
 
 
 def pytest_configure(config):

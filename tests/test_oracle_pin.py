@@ -47,6 +47,21 @@ def test_radiance_sums_bit_exact(scene):
     assert np.array_equal(O.tonemap_u8(band, 1.0 / spp), pin["u8"])
 
 
+@pytest.mark.parametrize("scene", ["synth60_list", "synth60_bvh"])
+def test_synthetic_grid_records_bit_exact(scene):
+    """The synthetic grid scene of the 4K configuration, built from the reference's classes by the
+    harness (oracle/ref_harness/harness.cpp synth_grid) at 14 401 primitives: as a plain
+    hittable_list the reference scans every primitive (hittable_list.h:29-43), under a bvh_node it
+    culls with its own boxes (bvh.h:77-88).  The oracle reproduces both sets of records bit for bit;
+    the two differ from each other only where the reference's own two traversals do."""
+    arrays, cam, ref_frame = load_scene(scene)
+    assert len(arrays.prims) == 14401
+    assert bytes(O.camera_initialize(cam)) == bytes(ref_frame)
+    rays, ref_hits, tmin, tmax = O.load_rays_file(os.path.join(GOLDEN, scene + ".rays"))
+    hits, _ = O.OracleScene(arrays).trace(rays, tmin, tmax, O.TRACE_REFERENCE)
+    assert hits.tobytes() == ref_hits.tobytes()
+
+
 def test_sphere_uv_known_answers():
     """The table the reference carries in sphere.h:100-102."""
     table = {(1, 0, 0): (0.50, 0.50), (-1, 0, 0): (0.00, 0.50), (0, 1, 0): (0.50, 1.00),
