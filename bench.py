@@ -46,13 +46,35 @@ PEAK_HBM_GBS = 8000.0
 # min / max, 1 per divide / sqrt / transcendental): the "algorithmic flops" of one launch are
 # these weights times the counts the instrumented kernel reports.
 W_BOX, W_SPHERE, W_SPHERE_HIT, W_QUAD = 24, 29, 35, 50
+# A scan tests a quad whose normal, u and v lie along coordinate axes (in its own space) with the
+# products by zero components dropped (rt_core.h quad_test_axis): 14 arithmetic operations and 7
+# comparisons where quad.h:32-91 spends about 50.  `frac` prices such tests at what is executed;
+# `frac_reference_weights` keeps the reference's 50.
+W_QUAD_AXIS = 21
+PEAK_LANE_OPS = 256 * 128 * 2.4e9  # lane-instructions per second: 256 CUs x 128 lanes x 2.4 GHz
+N_SIMD = 256 * 4
 W_SHADE = (30, 45, 70, 5)  # lambertian, metal, dielectric, diffuse_light
 W_CHECKER, W_NOISE, W_IMAGE, W_RAYGEN, W_RAY = 9, 7 * 160, 8, 30, 3
 
 
-def algorithmic_flops(st):
+def axis_quad_fraction(arrays, scanned):
+    """Share of the scene's quads that a scan tests with quad_test_axis (0 for scenes walked through a tree:
+    their leaves use the general test)."""
+    if not scanned:
+        return 0.0
+    import numpy as np
+    from raytracing_amd import abi
+    q = arrays.prims[arrays.prims["type"] == abi.RT_PRIM_QUAD]
+    if len(q) == 0:
+        return 0.0
+    u, v = q["b"] != 0, q["c"] != 0
+    axis = (u.sum(1) == 1) & (v.sum(1) == 1) & ~(u & v).any(1)
+    return float(axis.mean())
+
+
+def algorithmic_flops(st, axis_quads=0.0):
     f = W_BOX * st.box_tests + W_SPHERE * st.sphere_tests + W_SPHERE_HIT * st.sphere_hits
-    f += W_QUAD * st.quad_tests
+    f += (W_QUAD_AXIS * axis_quads + W_QUAD * (1.0 - axis_quads)) * st.quad_tests
     f += sum(w * n for w, n in zip(W_SHADE, st.shades))
     f += W_CHECKER * st.checker_evals + W_NOISE * st.noise_evals + W_IMAGE * st.image_evals
     f += W_RAYGEN * st.paths + W_RAY * st.rays
@@ -79,7 +101,8 @@ def measured_traffic(scene, width, height, spp, key="traffic_bytes_per_launch"):
             exact = abs(w["spp_per_launch"] - spp) < 1e-9
             if best is not None and best_exact and not exact:
                 continue
-            best = t[key] if key == "pmc" else float(t[key]) * spp / w["spp_per_launch"]
+            best = (dict(t[key], spp_per_launch=w["spp_per_launch"]) if key == "pmc"
+                    else float(t[key]) * spp / w["spp_per_launch"])
             best_exact = exact
         except (OSError, KeyError, ValueError, ZeroDivisionError):
             continue
@@ -94,7 +117,7 @@ def _sha16(path):
     return h.hexdigest()[:16]
 
 
-def cpu_baseline(scene, budget_paths, arrays=None, cam=None, port_too=True):
+def cpu_baseline(scene, budget_paths, arrays=None, cam=None, port_too=True, all_cores=False):
     """Times the reference renderer (oracle/_ref/rt_ref: the unmodified reference, compiled by
     __graft_entry__.build() where its sources exist and carried along as a binary) on one host
     core, and the oracle port beside it on a smaller sample; says which binary was timed.
@@ -130,10 +153,67 @@ def cpu_baseline(scene, budget_paths, arrays=None, cam=None, port_too=True):
             "mrays_per_s": st.rays / st.seconds * 1e-6, "binary": "oracle/liboracle.so",
             "sample": f"{scene} {w}x{h} at {pspp} spp, depth {cam.max_depth} "
                       f"({st.paths} paths, {st.seconds:.1f} s, oracle port, 1 thread)"}
+    if all_cores:
+        allc = all_cores_leg(osc, cam, max(1, spp // 2), f"{scene} {w}x{h}")
     if out is None:
-        return port
-    out["port"] = {k: port[k] for k in ("value", "mrays_per_s", "sample")}
+        out = port
+    else:
+        out["port"] = {k: port[k] for k in ("value", "mrays_per_s", "sample")}
+    if all_cores:
+        out["all_cores"] = allc
     return out
+
+
+def host_threads():
+    """Threads for the all-cores leg: the box's CPU share (OMP_NUM_THREADS there), not the whole machine."""
+    try:
+        n = int(os.environ.get("OMP_NUM_THREADS", "0"))
+    except ValueError:
+        n = 0
+    return n if n > 0 else (os.cpu_count() or 1)
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def all_cores_leg(osc, cam, spp, label):
+    """The port with the image's rows split across threads (counter-based sampler: one stream per path)."""
+    from tests import oracle_lib as O
+    n = host_threads()
+    _, st = osc.render(cam, spp, sampler=O.SAMPLER_CB, trace_mode=O.TRACE_REFERENCE, seed=1, n_threads=n)
+    return {"value": st.paths / st.seconds * 1e-6, "unit": "Mpaths/s", "cores": n, "cpu_model": cpu_model(),
+            "kind": "port", "mrays_per_s": st.rays / st.seconds * 1e-6,
+            "sample": f"{label} at {spp} spp ({st.paths} paths, {st.seconds:.1f} s, oracle port, {n} threads)"}
+
+
+def cpu_baseline_synth(budget_paths):
+    """The 10^6-primitive scene under one bvh_node, 480 x 270, oracle port: one thread and all cores."""
+    from raytracing_amd import abi
+    from tests import oracle_lib as O
+    prog = os.path.join(ROOT, "examples", "bin", "rt_scenes")
+    out = "/tmp/bench_synth1m_bvh.rtscene"
+    if not (os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(prog)):
+        subprocess.run([prog, "synth1m", "--half", "500", "--bvh", "1", "--dump", out], check=True, capture_output=True)
+    arrays = abi.SceneArrays.load(out)
+    cam = abi.load_camera_file(out + ".cam")[0]
+    cam.image_width = 480
+    w, h = cam.image_width, cam.image_height()
+    spp = max(1, int(round(budget_paths / (w * h))))
+    osc = O.OracleScene(arrays)
+    _, st = osc.render(cam, spp, sampler=O.SAMPLER_REF, trace_mode=O.TRACE_REFERENCE)
+    res = {"value": st.paths / st.seconds * 1e-6, "unit": "Mpaths/s", "cores": 1, "kind": "port",
+           "mrays_per_s": st.rays / st.seconds * 1e-6, "binary": "oracle/liboracle.so",
+           "sample": f"synth1m (1 000 001 primitives under one bvh_node) {w}x{h} at {spp} spp, depth {cam.max_depth} "
+                     f"({st.paths} paths, {st.seconds:.1f} s, oracle port, 1 thread)"}
+    res["all_cores"] = all_cores_leg(osc, cam, 4 * spp, f"synth1m {w}x{h}")
+    return res
 
 
 class Workload:
@@ -146,6 +226,7 @@ class Workload:
         self.torch, self.name, self.cam = torch, name, cam
         self.scene = binding.Scene(arrays, device=device_index)
         self.info = self.scene.info()
+        self.axis_quads = axis_quad_fraction(arrays, scanned=self.info.n_nodes == 0)
         self.H, self.W = cam.image_height(), cam.image_width
         self.dev = torch.device("cuda", device_index)
         self.render = spp_split.gpu_render_fn(self.scene, cam, seed=0, overlap=not serial)
@@ -211,28 +292,53 @@ class Workload:
         return f"{self.name} {self.W}x{self.H}, {spp_text}, max_depth {self.cam.max_depth}, {i.n_prims} primitives ({tree})"
 
 
-def roofline_of(wl, m, steps_total, spp_per_launch_hint):
+def roofline_of(wl, m, steps_total, spp_per_launch_hint, interval_s=None):
+    """interval_s: time between the starts of consecutive launches in the timed region (launches
+    overlap there, so it is shorter than a launch on its own)."""
     st = m["stats"]
-    alg = algorithmic_flops(st)
+    alg = algorithmic_flops(st, wl.axis_quads)
+    alg_ref = algorithmic_flops(st)
     avg_kernel_s = m["iso_ms"] / max(m["iso_launches"], 1) * 1e-3
     launches_per_step = max(m["n_launches"], 1) / steps_total
-    achieved = alg / launches_per_step / avg_kernel_s / 1e12 if avg_kernel_s > 0 else 0.0
+    per_launch = alg / launches_per_step
+    achieved = per_launch / avg_kernel_s / 1e12 if avg_kernel_s > 0 else 0.0
     spp_launch = spp_per_launch_hint / launches_per_step
     traffic = measured_traffic(wl.name, wl.W, wl.H, spp_launch)
-    return {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
-            "pmc": measured_traffic(wl.name, wl.W, wl.H, spp_launch, key="pmc"),
-            "hbm_gb_per_s": (traffic / avg_kernel_s * 1e-9) if traffic and avg_kernel_s > 0 else None,
-            "hbm_frac_of_peak": (traffic / avg_kernel_s * 1e-9 / PEAK_HBM_GBS) if traffic and avg_kernel_s > 0 else None,
-            "kernel": wl.kernel_name(), "kernel_ms_avg": avg_kernel_s * 1e3,
-            "kernel_ms_overlapped_avg": m["kernel_ms"] / max(m["n_launches"], 1),
-            "launches": m["n_launches"], "isolated_launches": m["iso_launches"],
-            "launches_per_step": launches_per_step,
-            "algorithmic_flops_per_launch": alg / launches_per_step,
-            "counts_per_step": {"paths": st.paths, "rays": st.rays, "box_tests": st.box_tests,
-                                "sphere_tests": st.sphere_tests, "sphere_hits": st.sphere_hits,
-                                "quad_tests": st.quad_tests, "shades": list(st.shades),
-                                "noise_evals": st.noise_evals, "image_evals": st.image_evals}}
+    pmc = measured_traffic(wl.name, wl.W, wl.H, spp_launch, key="pmc")
+    r = {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
+         # frac = frac_alone: the launch on its own (HIP events, no neighbour on the GPU); frac_by_interval:
+         # the same work over the interval at which launches complete while three are in flight
+         "frac": achieved / PEAK_FP32_VALU_TFLOPS, "frac_alone": achieved / PEAK_FP32_VALU_TFLOPS,
+         "frac_by_interval": (per_launch / interval_s / 1e12 / PEAK_FP32_VALU_TFLOPS) if interval_s else None,
+         "frac_reference_weights": (alg_ref / launches_per_step / avg_kernel_s / 1e12 / PEAK_FP32_VALU_TFLOPS)
+         if avg_kernel_s > 0 else 0.0,
+         "traffic": traffic, "traffic_unit": "bytes/launch", "pmc": pmc,
+         "hbm_gb_per_s": (traffic / avg_kernel_s * 1e-9) if traffic and avg_kernel_s > 0 else None,
+         "hbm_frac_of_peak": (traffic / avg_kernel_s * 1e-9 / PEAK_HBM_GBS) if traffic and avg_kernel_s > 0 else None,
+         "kernel": wl.kernel_name(), "kernel_ms_avg": avg_kernel_s * 1e3,
+         "kernel_ms_overlapped_avg": m["kernel_ms"] / max(m["n_launches"], 1),
+         "launches": m["n_launches"], "isolated_launches": m["iso_launches"],
+         "launches_per_step": launches_per_step,
+         "algorithmic_flops_per_launch": per_launch,
+         "counts_per_step": {"paths": st.paths, "rays": st.rays, "box_tests": st.box_tests,
+                             "sphere_tests": st.sphere_tests, "sphere_hits": st.sphere_hits,
+                             "quad_tests": st.quad_tests, "axis_aligned_quad_share": wl.axis_quads,
+                             "shades": list(st.shades),
+                             "noise_evals": st.noise_evals, "image_evals": st.image_evals}}
+    # Executed work, from the hardware counters of the committed profile of this workload (the
+    # instruction counts per launch scale with the paths; the time is this run's own):
+    #   cycles_per_valu_inst = SIMD cycles available during the launch / VALU wave-instructions per SIMD
+    #   executed_frac = active lane-instructions per second / (256 CUs x 128 lanes x 2.4 GHz)
+    for k in ("valu_busy_frac", "active_lane_frac", "cycles_per_valu_inst", "executed_frac"):
+        r[k] = None
+    if pmc and avg_kernel_s > 0:
+        scale = spp_launch / pmc.get("spp_per_launch", spp_launch)
+        insts = pmc["valu_wave_insts_per_launch"] * scale
+        r["valu_busy_frac"] = pmc["valu_busy_frac"]
+        r["active_lane_frac"] = pmc["active_lane_frac"]
+        r["cycles_per_valu_inst"] = avg_kernel_s * 2.4e9 * N_SIMD / insts
+        r["executed_frac"] = insts * 64 * pmc["active_lane_frac"] / avg_kernel_s / PEAK_LANE_OPS
+    return r
 
 
 def load_workload(name, width=0):
@@ -279,28 +385,27 @@ def run_other_configs(args, dev_index):
         m = wl.measure(0, spp, steps, 1, 3, 2, False, False)
         el = statistics.median(m["elapsed"])
         st = m["stats"]
-        r = roofline_of(wl, m, steps * 3, spp)
+        r = roofline_of(wl, m, steps * 3, spp, interval_s=el / steps / max(m["n_launches"] / (steps * 3), 1))
         entry = {"config": cfg, "workload": wl.describe(f"{spp} spp per step"), "steps": steps, "repeats": 3,
                  "value": st.paths * steps / el * 1e-6, "unit": "Mpaths/s", "mrays_per_s": st.rays * steps / el * 1e-6,
                  "rays_per_path": st.rays / max(st.paths, 1), "ms_per_step": el / steps * 1e3,
                  "kernel": r["kernel"], "kernel_ms_alone": r["kernel_ms_avg"], "launches_per_step": r["launches_per_step"],
-                 "roofline": {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "hbm_gb_per_s",
+                 "roofline": {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "frac_alone", "frac_by_interval",
+                                                "frac_reference_weights", "valu_busy_frac", "active_lane_frac",
+                                                "cycles_per_valu_inst", "executed_frac", "traffic", "hbm_gb_per_s",
                                                 "hbm_frac_of_peak", "algorithmic_flops_per_launch")}}
         wl.close()
         print(f"[bench] {name}: {entry['value']:.0f} Mpaths/s, kernel alone {entry['kernel_ms_alone']:.3f} ms, "
               f"frac {entry['roofline']['frac']:.4f}", file=sys.stderr, flush=True)
         if not args.no_cpu_baseline:
             if name == "synth1m":
-                # the reference has no such scene and its bvh_node constructor alone takes 10 s on a
-                # million primitives; the figure measured with the reference's classes in the
-                # authoring container is quoted instead of a timing here
-                entry["cpu_baseline"] = {"value": None, "unit": "Mpaths/s", "cores": 1, "kind": "reference",
-                                         "sample": "not timed in this run",
-                                         "measured_elsewhere": {"value": 0.070, "mrays_per_s": 0.43,
-                                                                "sample": "480x270 at 1 spp, 1 thread, measured in the authoring container"}}
+                # the reference's main.cpp has no such scene; the port is timed on the same million
+                # primitives held under one bvh_node (bvh.h:48-88), which is how a user of the reference
+                # would hold them, at 480 x 270
+                entry["cpu_baseline"] = cpu_baseline_synth(cpu_paths)
             else:
                 entry["cpu_baseline"] = cpu_baseline(name, cpu_paths, port_too=False)
-                print(f"[bench] {name}: CPU reference {entry['cpu_baseline']['value']:.3f} Mpaths/s", file=sys.stderr, flush=True)
+            print(f"[bench] {name}: CPU {entry['cpu_baseline']['kind']} {entry['cpu_baseline']['value']:.3f} Mpaths/s", file=sys.stderr, flush=True)
         out[name] = entry
     return out
 
@@ -385,14 +490,17 @@ def run_rank(args):
                        "spp_per_gpu_per_step": count, "max_depth": cam.max_depth,
                        "parallelism": f"spp-split x{world} + RCCL reduce (asynchronous, overlapping the next step)"
                        if world > 1 else "single GPU", "mode": "megakernel"},
-            "roofline": dict(roofline_of(wl, m, steps * args.repeats, count), overlap=not args.serial,
+            "roofline": dict(roofline_of(wl, m, steps * args.repeats, count,
+                                         interval_s=med / steps / max(m["n_launches"] / (steps * args.repeats), 1)),
+                             overlap=not args.serial,
                              launch_interval_ms=med / steps * 1e3 / max(m["n_launches"] / (steps * args.repeats), 1)),
         }
         print(f"[bench] {scene_name}: {out['value']:.0f} Mpaths/s over {joined} GPU(s)", file=sys.stderr)
     wl.close()
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scene_name, args.cpu_paths)
+            out["cpu_baseline"] = (cpu_baseline_synth(0.13e6) if scene_name == "synth1m"
+                                   else cpu_baseline(scene_name, args.cpu_paths, all_cores=True))
         if world == 1 and not args.no_configs and not strong and not args.scene:
             out["configs"] = run_other_configs(args, local_rank)
         print(json.dumps(out), flush=True)

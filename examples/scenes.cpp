@@ -2,7 +2,7 @@
 // (raytracing_amd/dropin), rendered by librt_amd.so.
 //
 //   rt_scenes <scene> [--spp N] [--width W] [--depth D] [--out file.png] [--dump file.rtscene]
-//                     [--hits file.rays out.hits]
+//                     [--hits file.rays out.hits] [--half N] [--bvh 1]   (the last two: synth1m)
 //
 // The seven scenes restate the reference's main.cpp:14-288 as data; `synth1m` is the
 // 1 000 001-primitive stress scene (no counterpart in the reference).  Random numbers that
@@ -317,6 +317,7 @@ int main(int argc, char **argv) {
         return 2;
     }
     int synth_half = 500;
+    bool synth_bvh = false; // --bvh 1: the world under one bvh_node, as a user of the reference would hold it
     for (int i = 2; i + 1 < argc; i += 2) {
         if (!strcmp(argv[i], "--hits") && i + 2 < argc) {
             g_rays_in = argv[i + 1];
@@ -328,6 +329,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--out")) g_out = argv[i + 1];
         else if (!strcmp(argv[i], "--dump")) setenv("RTAMD_DUMP_SCENE", argv[i + 1], 1);
         else if (!strcmp(argv[i], "--half")) synth_half = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "--bvh")) synth_bvh = atoi(argv[i + 1]) != 0;
     }
     std::string s = argv[1];
     if (s == "bouncing_spheres") bouncing_spheres();
@@ -339,7 +341,7 @@ int main(int argc, char **argv) {
     else if (s == "cornell_box") cornell_box();
     else if (s == "rotated_in_bvh") rotated_in_bvh();
     else if (s == "grove") grove();
-    else if (s == "synth1m") synth1m(synth_half);
+    else if (s == "synth1m") synth1m(synth_half, synth_bvh);
     else if (s == "synth60_list") synth1m(60, false, 480);
     else if (s == "synth60_bvh") synth1m(60, true, 480);
     else {

@@ -50,5 +50,18 @@ doc = {
                 "(SQ_ACTIVE_INST_VALU x 64); lds_bank_conflict_frac = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE",
     },
 }
+if "TCC_HIT_sum" in c:  # the cache pass (tools/pmc_scene.sh pmc3)
+    doc["pmc"]["caches"] = {
+        "tcp_total_cache_accesses_per_launch": int(c["TCP_TOTAL_CACHE_ACCESSES_sum"]),
+        "tcp_tcc_read_req_per_launch": int(c["TCP_TCC_READ_REQ_sum"]),
+        "tcc_hit_per_launch": int(c["TCC_HIT_sum"]), "tcc_miss_per_launch": int(c["TCC_MISS_sum"]),
+        "tcc_ea_rdreq_per_launch": int(c["TCC_EA_RDREQ_sum"]),
+        "l1_hit_frac": 1.0 - c["TCP_TCC_READ_REQ_sum"] / max(c["TCP_TOTAL_CACHE_ACCESSES_sum"], 1.0),
+        "l2_hit_frac": c["TCC_HIT_sum"] / max(c["TCC_HIT_sum"] + c["TCC_MISS_sum"], 1.0),
+        "l1_accesses_per_ray": c["TCP_TOTAL_CACHE_ACCESSES_sum"] / rays,
+        "note": "vector L1 (TCP) accesses and the requests it passes on to L2 (TCC); L2 hits, misses and reads from memory "
+                "(Infinity Cache / HBM), summed over all channels, per launch",
+    }
+doc["pmc"]["kernel_ms_alone_when_profiled"] = roof["kernel_ms_avg"]
 json.dump(doc, open(out, "w"), indent=1)
 print(json.dumps(doc["pmc"], indent=1))
