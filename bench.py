@@ -368,7 +368,7 @@ OTHER_CONFIGS = [
     ("config2", "checkered_spheres", 100, 10, 4.5e6), ("config2", "perlin_spheres", 100, 10, 1.8e6),
     ("config3", "earth", 100, 10, 9e6), ("config3", "quads", 100, 10, 6.4e6), ("config3", "simple_light", 100, 10, 3.6e6),
     ("config4", "cornell_box", 2048, 1, 2.88e6),   # one GPU's share of 16 384 spp over 8
-    ("config5", "synth1m", 8, 2, 0.13e6),           # 3840x2160, 8 of the 1024 spp
+    ("config5", "synth1m", 8, 2, 1.3e6),           # 3840x2160, 8 of the 1024 spp
 ]
 
 
@@ -499,7 +499,7 @@ def run_rank(args):
     wl.close()
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = (cpu_baseline_synth(0.13e6) if scene_name == "synth1m"
+            out["cpu_baseline"] = (cpu_baseline_synth(1.3e6) if scene_name == "synth1m"
                                    else cpu_baseline(scene_name, args.cpu_paths, all_cores=True))
         if world == 1 and not args.no_configs and not strong and not args.scene:
             out["configs"] = run_other_configs(args, local_rank)

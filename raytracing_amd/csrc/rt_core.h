@@ -957,11 +957,12 @@ template <bool COUNT> RT_HD NodePlanes node_planes_global(const f4 *node, const 
     r.n_children = COUNT ? *(const RT_AS_GLOBAL int *)(n + 112) : 0;
     return r;
 }
+template <bool COUNT, class ST, bool SPILL>
+RT_HD void trav_inner_planes(Trav &tv, const NodePlanes &np, float tmin, const ST &st, int ref_bits, Cnt<COUNT> &cn);
 // NODES_IN_LDS: `nodes` itself is a copy in LDS (the whole scene is); else it is global memory.
 template <bool COUNT, class ST, bool TOP, bool SPILL, int NODE_F4 = RT_NODE_F4>
 RT_HD void trav_inner(Trav &tv, const f4 *nodes, float tmin, const ST &st, int ref_bits, Cnt<COUNT> &cn,
                       const f4 *top = nullptr, int n_top = 0) {
-    typedef typename ST::elem T;
     NodePlanes np;
     if (TOP && tv.ref < n_top) { // two explicit paths: LDS reads and global loads, no flat addressing
         np = node_planes_lds<COUNT>(top + lds_node_words(tv.ref), tv.br);
@@ -970,6 +971,12 @@ RT_HD void trav_inner(Trav &tv, const f4 *nodes, float tmin, const ST &st, int r
     } else {
         np = node_planes_global<COUNT>(nodes + (size_t)tv.ref * NODE_F4, tv.br);
     }
+    trav_inner_planes<COUNT, ST, SPILL>(tv, np, tmin, st, ref_bits, cn);
+}
+// The step itself, from the planes and references of the node wherever they were read from.
+template <bool COUNT, class ST, bool SPILL>
+RT_HD void trav_inner_planes(Trav &tv, const NodePlanes &np, float tmin, const ST &st, int ref_bits, Cnt<COUNT> &cn) {
+    typedef typename ST::elem T;
     if constexpr (COUNT) cn.box += np.n_children;
     const f4 px = np.px, qx = np.qx, py = np.py, qy = np.qy, pz = np.pz, qz = np.qz, q6 = np.refs;
     float e0, e1, e2, e3;

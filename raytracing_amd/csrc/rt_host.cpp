@@ -184,7 +184,7 @@ LaunchGeom choose_geom(rt_scene *s, uint32_t flags) {
     rtc::DevScene &dv = s->dev;
     const bool bvh = dv.traversal == rtc::TRAV_BVH;
     const int cap = bvh ? RT_STACK_CAP(s->info.bvh_depth) : 0; // stack entries a ray can need
-    const size_t geom_bytes = ((size_t)dv.n_slots * dv.slot_f4 + (size_t)dv.n_nodes * RT_NODE_LDS_F4) * sizeof(f4);
+
     const size_t all_bytes = scene_lds_bytes(dv);
     const int block = std::max(64, std::min(1024, env_int("RT_AMD_BLOCK", 1024) / 64 * 64));
     const int threads_per_cu = rtl::mega_waves_per_simd() * 256;
@@ -238,14 +238,24 @@ LaunchGeom choose_geom(rt_scene *s, uint32_t flags) {
         int bits = 1;
         while ((1ll << bits) < std::max<long long>(dv.n_nodes, 2ll * (dv.n_slots + dv.n_inst + 1))) bits++;
         dv.ref_bits = std::max(16, std::min(32, bits + 1));
-        lg.stack_lds_entries = bvh ? std::max(4, std::min(cap, env_int("RT_AMD_LDS_STACK", 16))) : 0;
+        // Cooperative node fetch (rt_sched.h coop_fetch_nodes), RT_AMD_COOP=1: 4 KB of staging per wave,
+        // which a shorter LDS part of the stacks makes room for; the tree's top is then not kept in LDS.
+        // Off by default: measured 34 % slower than the lane-by-lane loads on the 10^6-primitive scene
+        // (the memory pipeline takes a wave's 64 x 16-byte requests four lanes a cycle however they
+        // coalesce, so eight cooperative loads cost what seven private ones do, and the trip through
+        // LDS comes on top).  Two-level scenes always keep the lane-by-lane loads.
+        const size_t coop_bytes = (size_t)(block / 64) * RT_COOP_F4_PER_WAVE * sizeof(f4);
+        const bool coop = bvh && ring_bytes && block == 1024 && env_int("RT_AMD_COOP", 0) != 0 && s->dev.n_inst == 0;
+        lg.stack_lds_entries = bvh ? std::max(4, std::min(cap, env_int("RT_AMD_LDS_STACK", coop ? 10 : 16))) : 0;
         size_t stack = (size_t)lg.stack_lds_entries * RT_MEGA_MAX_THREADS * sizeof(int);
         bpc = bpc_target;
         while (bpc > 1 && lds_budget(bpc) < stack + ring_bytes) bpc--;
         size_t budget = lds_budget(bpc);
         lg.ring = ring_bytes && stack + ring_bytes <= budget;
         used = stack;
-        if (bvh && s->tree_top > 0 && env_int("RT_AMD_TREE_TOP", 1) != 0) {
+        if (coop && lg.ring && bpc == 1 && stack + ring_bytes + coop_bytes <= budget) {
+            lg.coop = true;
+        } else if (bvh && s->tree_top > 0 && env_int("RT_AMD_TREE_TOP", 1) != 0) {
             size_t taken = stack + (lg.ring ? ring_bytes : 0);
             size_t room = budget > taken ? budget - taken : 0;
             dv.n_top = (int)std::min<size_t>((size_t)s->tree_top, room / (RT_NODE_LDS_F4 * sizeof(f4)));
@@ -262,6 +272,10 @@ LaunchGeom choose_geom(rt_scene *s, uint32_t flags) {
     used = (used + 15) / 16 * 16;
     lg.ring_f4 = (int)(used / sizeof(f4));
     lg.lds_bytes = (int)(used + (lg.ring ? ring_bytes : 0));
+    if (lg.coop) {
+        lg.coop_f4 = lg.lds_bytes / (int)sizeof(f4);
+        lg.lds_bytes += (block / 64) * RT_COOP_F4_PER_WAVE * (int)sizeof(f4);
+    }
     lg.lds_bytes = std::max(lg.lds_bytes, 16);
     lg.grid = s->n_cu * std::max(bpc, 1);
     return lg;
@@ -592,6 +606,7 @@ RenderParams base_params(int W, int H, int n_pixels, const rt_render_opts *opts,
     rp.n_units = rp.n_strips * (unsigned)sc_n;
     rp.pixel_major = tn.unit_order;
     rp.ring_f4 = lg.ring_f4;
+    rp.coop_f4 = lg.coop_f4;
     rp.stack_lds_entries = lg.stack_lds_entries;
     rp.scheduler = tn.scheduler;
     rp.min_ready = tn.min_ready;

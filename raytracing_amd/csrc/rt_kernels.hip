@@ -188,7 +188,8 @@ render_mega(DevScene sc, DevCamera cam, RenderParams rp) {
 
 // ------------------------------------------------------------------------------------------
 // BVH scenes: traversal and shading are decoupled (see the header comment).
-template <bool LDS_SCENE, bool COUNT, bool RING>
+// COOP: scenes read from HBM whose waves read their nodes together (rt_sched.h coop_fetch_nodes).
+template <bool LDS_SCENE, bool COUNT, bool RING, bool COOP = false>
 __global__ void __launch_bounds__(RT_MEGA_MAX_THREADS, RT_MEGA_WAVES_PER_SIMD)
 render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
     extern __shared__ f4 smem[];
@@ -210,6 +211,7 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
     const Stack st = lane_stack<StackT, SPILL, RT_MEGA_MAX_THREADS>(free_lds, sc, rp.stack_lds_entries, rp.stack_spill);
     // RING: the camera rays of the wave's current unit, structure of arrays over its 64 paths
     f4 *ring = RING ? smem + rp.ring_f4 + (size_t)(threadIdx.x >> 6) * RT_RING_F4_PER_WAVE : nullptr;
+    f4 *coop_stage = COOP ? smem + rp.coop_f4 + (size_t)(threadIdx.x >> 6) * RT_COOP_F4_PER_WAVE : nullptr;
 
     const int lane = threadIdx.x & 63;
     const unsigned long long lane_mask_lt = (1ull << lane) - 1ull;
@@ -353,8 +355,8 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
             continue;
         }
         // ---- traversal steps until enough lanes wait for shading ------------------------------
-        wave_traverse<LDS_SCENE, COUNT, Stack, SPILL>(state, tv, pend, ps.ray, sc, vw, st, 0.001f, min_ready, leaf_min,
-                                                       blocked_min, !pool_dry, cn, ss);
+        wave_traverse<LDS_SCENE, COUNT, Stack, SPILL, COOP>(state, tv, pend, ps.ray, sc, vw, st, 0.001f, min_ready, leaf_min,
+                                                             blocked_min, !pool_dry, cn, ss, coop_stage);
     }
     };
     run_phase(std::false_type{});
@@ -513,7 +515,7 @@ trace_batch(DevScene sc, const rt_ray *rays, long long n_rays, float tmin, float
 // render_mega_bvh (wave_traverse: blocks of node steps, parked leaves), with the caller's rays
 // in place of paths.  A wave takes 64 consecutive rays at a time from a global counter; lanes
 // whose ray is done write its record and take the next one.
-template <bool LDS_SCENE>
+template <bool LDS_SCENE, bool COOP = false>
 __global__ void __launch_bounds__(RT_MEGA_MAX_THREADS, RT_MEGA_WAVES_PER_SIMD)
 trace_sched(DevScene sc, RenderParams rp, const rt_ray *rays, long long n_rays, float tmin, float tmax, rt_hit *hits) {
     extern __shared__ f4 smem[];
@@ -531,6 +533,7 @@ trace_sched(DevScene sc, RenderParams rp, const rt_ray *rays, long long n_rays, 
     constexpr bool SPILL = !LDS_SCENE;
     typedef TravStack<StackT, RT_MEGA_MAX_THREADS> Stack;
     const Stack st = lane_stack<StackT, SPILL, RT_MEGA_MAX_THREADS>(free_lds, sc, rp.stack_lds_entries, rp.stack_spill);
+    f4 *coop_stage = COOP ? smem + rp.coop_f4 + (size_t)(threadIdx.x >> 6) * RT_COOP_F4_PER_WAVE : nullptr;
     const int lane = threadIdx.x & 63;
     const unsigned long long lane_mask_lt = (1ull << lane) - 1ull;
     const unsigned long long n_batches = (unsigned long long)((n_rays + 63) / 64);
@@ -591,8 +594,8 @@ trace_sched(DevScene sc, RenderParams rp, const rt_ray *rays, long long n_rays, 
             if (exhausted) break;
             continue;
         }
-        wave_traverse<LDS_SCENE, false, Stack, SPILL>(state, tv, pend, ray, sc, vw, st, tmin, rp.min_ready, rp.leaf_min,
-                                                       rp.blocked_min, !exhausted, cn, ss);
+        wave_traverse<LDS_SCENE, false, Stack, SPILL, COOP>(state, tv, pend, ray, sc, vw, st, tmin, rp.min_ready, rp.leaf_min,
+                                                             rp.blocked_min, !exhausted, cn, ss, coop_stage);
     }
 }
 
@@ -645,6 +648,17 @@ hipError_t RT_LAUNCH_NAME(launch_mega)(const DevScene &sc, const DevCamera &cam,
     if (rp.scheduler == 0)
         return lg.lds_scene ? launch_mega_tc<TRAV_BVH, true>(sc, cam, rp, lg, stream)
                             : launch_mega_tc<TRAV_BVH, false>(sc, cam, rp, lg, stream);
+#ifndef RT_INST
+    if (lg.coop && !lg.lds_scene) { // (the host only sets it together with the rings; never for two-level scenes)
+        if (rp.counters)
+            hipLaunchKernelGGL((render_mega_bvh<false, true, true, true>), dim3(lg.grid), dim3(lg.block), lg.lds_bytes,
+                               stream, sc, cam, rp);
+        else
+            hipLaunchKernelGGL((render_mega_bvh<false, false, true, true>), dim3(lg.grid), dim3(lg.block), lg.lds_bytes,
+                               stream, sc, cam, rp);
+        return hipGetLastError();
+    }
+#endif
     // the ring variant starts every path with depth > 0 (camera.h:141 is the other one's business)
     if (lg.ring && cam.max_depth > 0)
         return lg.lds_scene ? launch_mega_bvh_tc<true, true>(sc, cam, rp, lg, stream)
@@ -704,11 +718,21 @@ hipError_t RT_LAUNCH_NAME(set_mega_lds_limit)(int bytes) {
     RT_SET2(false, true)
     RT_SET2(false, false)
 #undef RT_SET2
+#ifndef RT_INST
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void *)render_mega_bvh<false, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void *)render_mega_bvh<false, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+#endif
 #ifndef RT_LEAN
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void *)trace_sched<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void *)trace_sched<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+#ifndef RT_INST
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void *)trace_sched<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+#endif
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void *)trace_batch<TRAV_BVH>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 #endif
@@ -761,6 +785,11 @@ hipError_t RT_LAUNCH_NAME(launch_trace_sched)(const DevScene &sc, const RenderPa
     if (lg.lds_scene)
         hipLaunchKernelGGL((trace_sched<true>), dim3(lg.grid), dim3(lg.block), lg.lds_bytes, stream, sc, rp, rays, n,
                            tmin, tmax, hits);
+#ifndef RT_INST
+    else if (lg.coop)
+        hipLaunchKernelGGL((trace_sched<false, true>), dim3(lg.grid), dim3(lg.block), lg.lds_bytes, stream, sc, rp, rays, n,
+                           tmin, tmax, hits);
+#endif
     else
         hipLaunchKernelGGL((trace_sched<false>), dim3(lg.grid), dim3(lg.block), lg.lds_bytes, stream, sc, rp, rays, n,
                            tmin, tmax, hits);

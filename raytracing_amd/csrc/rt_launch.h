@@ -34,6 +34,7 @@ struct RenderParams {
     int pixel_major;               // order of the units: 0 sample-major, 1 pixel-major
     const unsigned *strip_order;   // pixel-major: the strips in the order they are handed out (null: as they lie)
     int ring_f4;                   // camera-ray rings (LaunchGeom::ring): their offset in dynamic LDS, 16-byte words
+    int coop_f4;                   // staging areas of the cooperative node fetch (LaunchGeom::coop): their offset
     int stack_lds_entries;         // BVH scenes: stack entries per lane kept in LDS
     int *stack_spill;              // ... the rest: [block][entry][lane of the block] (null: none)
     rtc::f4 *stage;                // [sample_count][n_pixels] {r g b rays}
@@ -64,8 +65,13 @@ struct LaunchGeom {
     // linear scenes that are mostly scan: the kernel built for 8 waves per SIMD.  Pipelined launches
     // keep one workgroup per CU each (two launches share a CU); a launch on its own starts two.
     bool dense = false;
+    // scenes read from HBM: the waves read their nodes together through per-wave staging areas in LDS
+    // (rt_sched.h coop_fetch_nodes); the tree's top is then not cached in LDS
+    bool coop = false;
+    int coop_f4 = 0; // offset of the staging areas in dynamic LDS, in 16-byte words
 };
 #define RT_RING_F4_PER_WAVE (3 * 64) // {origin, time} {direction, sampler state} {pixel, local sample, -, -}
+#define RT_COOP_F4_PER_WAVE (32 * 8) // staging of the cooperative node fetch: 32 nodes of 8 x 16 bytes per wave
 
 // Path state of the wavefront variant: structure-of-arrays over the in-flight path slots.
 struct WfBuffers {

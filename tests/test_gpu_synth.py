@@ -114,6 +114,32 @@ def test_reference_records_of_the_synthetic_grid(scene):
         sc.close()
 
 
+def test_cooperative_node_fetch_gives_the_same_answers(monkeypatch):
+    """RT_AMD_COOP=1 (read by rt_scene_create): the waves of the kernels that walk a tree in HBM read
+    their nodes together, eight lanes per 128-byte node, through a staging area in LDS
+    (rt_sched.h coop_fetch_nodes) instead of lane by lane.  Off by default (slower); kept selectable
+    and held to the same bar: the reference's records bit for bit through the scheduled batch
+    kernel, and the same image as the default kernel bit for bit."""
+    from tests.test_gpu_trace import _check_records
+    from tests.conftest import GOLDEN, load_scene
+    B = _binding()
+    arrays, cam, _ = load_scene("synth60_bvh")
+    rays, ref_hits, tmin, tmax = O.load_rays_file(os.path.join(GOLDEN, "synth60_bvh.rays"))
+    plain = B.Scene(arrays)
+    monkeypatch.setenv("RT_AMD_COOP", "1")
+    coop = B.Scene(arrays)
+    monkeypatch.delenv("RT_AMD_COOP")
+    _check_records(coop.trace(rays, tmin, tmax, sched=True), ref_hits)
+    cam.image_width = 320
+    a, st_a = plain.render(cam, 4, seed=6)
+    b, st_b = coop.render(cam, 4, seed=6)
+    assert st_a.rays == st_b.rays and np.array_equal(a, b)
+    c, st_c = coop.render(cam, 4, seed=6, counters=True)  # the instrumented variant of the same kernel
+    assert np.array_equal(a, c) and st_c.box_tests > 0
+    plain.close()
+    coop.close()
+
+
 def test_converged_image_of_the_synthetic_grid_psnr():
     """The reference's own render of synth60_bvh (480 x 270, 1024 spp, tests/golden/synth60_bvh.ref.png,
     oracle/make_golden.py images synth60_bvh) against the GPU's: PSNR >= 40 dB on the 8-bit image."""

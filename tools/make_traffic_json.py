@@ -55,10 +55,11 @@ if "TCC_HIT_sum" in c:  # the cache pass (tools/pmc_scene.sh pmc3)
         "tcp_total_cache_accesses_per_launch": int(c["TCP_TOTAL_CACHE_ACCESSES_sum"]),
         "tcp_tcc_read_req_per_launch": int(c["TCP_TCC_READ_REQ_sum"]),
         "tcc_hit_per_launch": int(c["TCC_HIT_sum"]), "tcc_miss_per_launch": int(c["TCC_MISS_sum"]),
-        "tcc_ea_rdreq_per_launch": int(c["TCC_EA_RDREQ_sum"]),
+        "tcc_ea_rdreq_per_launch": int(c["TCC_EA_RDREQ_sum"]) if "TCC_EA_RDREQ_sum" in c else (int(c["TCC_EA0_RDREQ_sum"]) if "TCC_EA0_RDREQ_sum" in c else None),
         "l1_hit_frac": 1.0 - c["TCP_TCC_READ_REQ_sum"] / max(c["TCP_TOTAL_CACHE_ACCESSES_sum"], 1.0),
         "l2_hit_frac": c["TCC_HIT_sum"] / max(c["TCC_HIT_sum"] + c["TCC_MISS_sum"], 1.0),
         "l1_accesses_per_ray": c["TCP_TOTAL_CACHE_ACCESSES_sum"] / rays,
+        "l1_accesses_per_cycle_and_cu": c["TCP_TOTAL_CACHE_ACCESSES_sum"] / 256.0 / (roof["kernel_ms_avg"] * 1e-3 * 2.4e9),
         "note": "vector L1 (TCP) accesses and the requests it passes on to L2 (TCC); L2 hits, misses and reads from memory "
                 "(Infinity Cache / HBM), summed over all channels, per launch",
     }

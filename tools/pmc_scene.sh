@@ -13,7 +13,7 @@ timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt 
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE --output-format csv -d $O/pmc1 -- $B > $O/pmc1.log 2>&1 || { echo "pmc1 failed"; tail -n 5 $O/pmc1.log; exit 1; }
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS --output-format csv -d $O/pmc2 -- $B > $O/pmc2.log 2>&1 || { echo "pmc2 failed"; tail -n 5 $O/pmc2.log; exit 1; }
 # vector L1 and L2: requests the L1 sends on to L2, L1 accesses, L2 hits / misses, L2 reads from memory
-timeout -s KILL 120 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_HIT_sum TCC_MISS_sum TCC_EA_RDREQ_sum --output-format csv -d $O/pmc3 -- $B > $O/pmc3.log 2>&1 || { echo "pmc3 failed"; tail -n 5 $O/pmc3.log; exit 1; }
+timeout -s KILL 120 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum --output-format csv -d $O/pmc3 -- $B > $O/pmc3.log 2>&1 || { echo "pmc3 failed"; tail -n 5 $O/pmc3.log; exit 1; }
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_f -- $B > $O/pmc_f.log 2>&1 || { echo "pmc_f failed"; exit 1; }
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_w -- $B > $O/pmc_w.log 2>&1 || { echo "pmc_w failed"; exit 1; }
 find $O/kt -name "*kernel_stats.csv" -exec head -6 {} \; > $O/kernel_stats.csv
