@@ -130,6 +130,14 @@ RT_HD f3 sh_unit(f3 v) { // vec3.h:124-126
 #else
 #define RT_WAVE_ANY(x) (x)
 #endif
+// -DRT_ISA_MARKS: comment lines in the generated assembly at the phase boundaries of the render
+// kernels, for tools/opcode_hist.py (they emit no instruction, but they pin the order of the code around
+// them: not for production builds).
+#if defined(RT_ISA_MARKS) && defined(__HIP_DEVICE_COMPILE__)
+#define RT_MARK(name) asm volatile("; RT_MARK " name ::: "memory")
+#else
+#define RT_MARK(name) ((void)0)
+#endif
 #define RT_PI 3.1415926535897932385f
 #define RT_INF __builtin_huge_valf()
 

@@ -256,6 +256,7 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
             }
         }
         // ---- shade the lanes whose closest hit is known ---------------------------------------
+        RT_MARK("shade");
         RT_TICK();
         bool begin = false; // the lane has a new ray: scattered here, or a camera ray below
         if (state == ST_READY) {
@@ -275,6 +276,7 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
         }
         RT_TOCK(c_shade);
         RT_TICK();
+        RT_MARK("start");
         // ---- hand new paths to idle lanes -------------------------------------------------------
         unsigned long long need = TAIL ? 0ull : __ballot(state == ST_IDLE);
         // starting paths (camera ray, sampler seed) is batched like everything else: wait
@@ -341,11 +343,13 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
             }
         }
         // scattered rays and camera rays set their traversal up together (more lanes per instruction)
+        RT_MARK("begin");
         if (begin) {
             trav_begin(tv, ps.ray, RT_INF, sc);
             trav_test_big<COUNT>(tv, sc, vw, ps.ray, 0.001f, cn);
         }
         RT_TOCK(c_regen);
+        RT_MARK("loop");
         const bool pool_dry = TAIL || (wp.exhausted && wp.k >= wp.k_end);
         if constexpr (!TAIL) {
             if (pool_dry) return; // on to the tail copy of the loop

@@ -122,6 +122,7 @@ __device__ __forceinline__ void wave_traverse(int &state, Trav &tv, Parked &pend
     // and a lane does not walk on past one (rt_core.h trav_barrier)
     const bool inst_scene = RT_FEAT_INSTANCE && sc.n_inst > 0;
     for (;;) {
+        RT_MARK("sched");
         unsigned long long tmask = __ballot(state == ST_TRAV);
         if (tmask == 0ull) break;
         unsigned long long rmask = __ballot(state == ST_READY || (state == ST_IDLE && idle_counts));
@@ -138,6 +139,7 @@ __device__ __forceinline__ void wave_traverse(int &state, Trav &tv, Parked &pend
             c_mark = clock64();
         }
         const bool trav = state == ST_TRAV;
+        RT_MARK("node");
 #pragma unroll
         for (int k = 0; k < RT_INNER_UNROLL; k++) {
             if constexpr (COOP) {
@@ -158,6 +160,7 @@ __device__ __forceinline__ void wave_traverse(int &state, Trav &tv, Parked &pend
             ss.c_inner += now - c_mark;
             c_mark = now;
         }
+        RT_MARK("leaf");
         const bool blocked = trav && tv.ref < 0 && tv.ref != RT_TRAV_DONE; // another leaf, no slot left
         const bool has_pend = trav && pend.a != 0;
         const bool at_barrier = inst_scene && trav && trav_is_barrier(sc, tv.ref);
@@ -180,6 +183,7 @@ __device__ __forceinline__ void wave_traverse(int &state, Trav &tv, Parked &pend
             }
         }
         if constexpr (COUNT) ss.c_leaf += clock64() - c_mark;
+        RT_MARK("sched");
         if (trav && tv.ref == RT_TRAV_DONE && pend.a == 0) state = ST_READY;
     }
 }
