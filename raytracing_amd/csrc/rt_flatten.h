@@ -867,6 +867,27 @@ inline int flatten_scene(const rt_scene_desc *d, uint32_t flags, HostScene &out,
             if (smax > 1.0f && !linear) slack_len[i] = std::max(slack_len[i], slack_len[i] * smax);
     }
 
+    // Binary tree over a set of boxes: the external (device-side) builder where one is given and it
+    // delivers a tree of the expected shape, else the host's binned-SAH builder.
+    bool any_external = false, all_external = true;
+    auto build_binary = [&](const std::vector<Box3> &bx, const std::vector<int> &ty) {
+        const int cnt = (int)bx.size();
+        BvhOut bo;
+        bool built = false;
+        if (external) {
+            built = external(bx, ty, bo) && (int)bo.leaf_order.size() == cnt &&
+                    (int)bo.nodes.size() == 4 * (cnt - 1) && bo.max_inner_depth <= kMaxInnerDepth;
+            if (!built) bo = BvhOut();
+        }
+        if (!built) {
+            BvhBuilder builder(bx, ty);
+            bo = builder.run();
+        }
+        any_external = any_external || built;
+        all_external = all_external && built;
+        return bo;
+    };
+
     out.n_prims = n;
     out.slot_f4 = slot_f4;
     out.linear = linear;
@@ -912,8 +933,7 @@ inline int flatten_scene(const rt_scene_desc *d, uint32_t flags, HostScene &out,
             if (cnt == 1) {
                 sub.leaf_order = {first};
             } else {
-                BvhBuilder builder(sb, st);
-                BvhOut bo = builder.run();
+                BvhOut bo = build_binary(sb, st);
                 sub.wide = collapse_to_wide(bo.nodes);
                 for (int local : bo.leaf_order) sub.leaf_order.push_back(first + local);
                 max_sub_levels = std::max(max_sub_levels, sub.wide.levels);
@@ -976,8 +996,7 @@ inline int flatten_scene(const rt_scene_desc *d, uint32_t flags, HostScene &out,
             top.n_nodes = 1;
             top.levels = 1;
         } else {
-            BvhBuilder builder(ib, it);
-            BvhOut bo = builder.run();
+            BvhOut bo = build_binary(ib, it);
             top = collapse_to_wide(bo.nodes);
             top_order = bo.leaf_order;
         }
@@ -1034,6 +1053,7 @@ inline int flatten_scene(const rt_scene_desc *d, uint32_t flags, HostScene &out,
         out.n_nodes = node_total;
         out.bvh_depth = top.levels + max_sub_levels + 1; // (+1: the mark on the stack while inside an instance)
         out.n_top = 0;
+        out.external_nodes = any_external && all_external; // every tree of the scene came from the external builder
     } else if (linear) {
         slots = geom;
         for (int i = 0; i < n; i++) meta[i] = i4{types[i], d->prims[i].material, d->prims[i].xform, i};
@@ -1071,18 +1091,8 @@ inline int flatten_scene(const rt_scene_desc *d, uint32_t flags, HostScene &out,
             tb = &rest_boxes_store;
             tt = &rest_types_store;
         }
-        BvhOut bo;
-        bool built = false;
-        if (external) {
-            built = external(*tb, *tt, bo) && (int)bo.leaf_order.size() == n_rest &&
-                    (int)bo.nodes.size() == 4 * (n_rest - 1) && bo.max_inner_depth <= kMaxInnerDepth;
-            if (!built) bo = BvhOut();
-        }
-        if (!built) {
-            BvhBuilder builder(*tb, *tt);
-            bo = builder.run();
-        }
-        out.external_nodes = built;
+        BvhOut bo = build_binary(*tb, *tt);
+        out.external_nodes = any_external;
         out.n_bin_nodes = (int)(bo.nodes.size() / 4);
         Wide wide = collapse_to_wide(bo.nodes);
         nodes = std::move(wide.nodes);

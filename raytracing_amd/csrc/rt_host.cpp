@@ -484,6 +484,7 @@ static int impl_rt_scene_create(const rt_scene_desc *d, int device, uint32_t fla
     if (e == hipSuccess) e = rtl::set_mega_lds_limit_lean(kMaxLdsBytes);
     if (e == hipSuccess) e = rtl::set_mega_lds_limit_inst(kMaxLdsBytes);
     if (e == hipSuccess) e = rtl::set_wavefront_lds_limit(kMaxLdsBytes);
+    if (e == hipSuccess) e = rtl::set_wavefront_lds_limit_inst(kMaxLdsBytes);
     if (e != hipSuccess) {
         rt_scene_destroy(s);
         return fail(RT_ERR_HIP, "kernel set-up (static scratch block, dynamic LDS limit): %s", hipGetErrorString(e));
@@ -663,8 +664,6 @@ static int impl_rt_render_device(rt_scene *s, const rt_camera_desc *cam, const r
     const bool wavefront = opts->mode == RT_MODE_WAVEFRONT;
     if (wavefront && (opts->flags & RT_RENDER_COUNTERS))
         return fail(RT_ERR_UNSUPPORTED, "the wavefront variant has no instrumented build");
-    if (wavefront && s->dev.n_inst > 0) // (its hit records carry no instance)
-        return fail(RT_ERR_UNSUPPORTED, "the wavefront variant does not render scenes with instances");
     rtc::DevCamera dc;
     int n_pixels = 0;
     int rc = check_render_args(s, cam, opts, dc, n_pixels);
@@ -821,7 +820,10 @@ static int impl_rt_render_device(rt_scene *s, const rt_camera_desc *cam, const r
             RT_HIP(hipMemsetAsync(s->stage[b], 0, per_sample * sc_n, stream));
         } else {
             int rounds = 0;
-            RT_HIP(rtl::render_wavefront(dev, dc, rp, s->wf, wf_slots, lg, s->wf_host_cnt, stream, &rounds));
+            if (dev.n_inst > 0)
+                RT_HIP(rtl::render_wavefront_inst(dev, dc, rp, s->wf, wf_slots, lg, s->wf_host_cnt, stream, &rounds));
+            else
+                RT_HIP(rtl::render_wavefront(dev, dc, rp, s->wf, wf_slots, lg, s->wf_host_cnt, stream, &rounds));
             wf_rounds += rounds;
         }
         if (stats) RT_HIP(hipEventRecord(ev.b, stream));

@@ -91,6 +91,10 @@ hipError_t set_wavefront_lds_limit(int bytes);
 hipError_t render_wavefront(const rtc::DevScene &sc, const rtc::DevCamera &cam, const RenderParams &rp,
                             const WfBuffers &wf, unsigned n_slots, const LaunchGeom &lg, unsigned *host_cnt,
                             hipStream_t stream, int *rounds_out);
+hipError_t set_wavefront_lds_limit_inst(int bytes);
+hipError_t render_wavefront_inst(const rtc::DevScene &sc, const rtc::DevCamera &cam, const RenderParams &rp,
+                                 const WfBuffers &wf, unsigned n_slots, const LaunchGeom &lg, unsigned *host_cnt,
+                                 hipStream_t stream, int *rounds_out);
 hipError_t launch_mega(const rtc::DevScene &sc, const rtc::DevCamera &cam, const RenderParams &rp,
                        const LaunchGeom &lg, hipStream_t stream);
 hipError_t set_mega_lds_limit(int bytes);

@@ -182,6 +182,8 @@ wf_trace(DevScene sc, WfBuffers wf, const int *q_trace_cur, RenderParams rp) {
         for (;;) {
             if (state == ST_READY) {
                 *reinterpret_cast<float2 *>(&wf.aux[slot]) = float2{tv.best_t, __builtin_bit_cast(float, tv.best_slot)};
+                // (the instance the primitive was hit in travels in the spare word beside the direction)
+                if (RT_FEAT_INSTANCE) wf.state[4 * (size_t)slot + 1].w = __builtin_bit_cast(float, tv.best_inst);
                 wf.key[mine] = tv.best_slot < 0 ? (int)Q_MISS : RT_KIND_MAT(vw.rec_i[tv.best_slot].x);
                 state = ST_IDLE;
             }
@@ -283,6 +285,7 @@ wf_shade(DevScene sc, DevCamera cam, RenderParams rp, WfBuffers wf, int *q_trace
             TraceHit h;
             h.t = __builtin_bit_cast(float, ax.x);
             h.slot = ax.y;
+            if (RT_FEAT_INSTANCE) h.inst = __builtin_bit_cast(int, d.w);
             if (path_after_trace<false>(sc, vw, cam, ps, h, cn)) {
                 key = 0;
                 st[0] = f4{ps.ray.o.x, ps.ray.o.y, ps.ray.o.z, ps.ray.tm};
@@ -317,7 +320,15 @@ __global__ void wf_init(WfBuffers wf, unsigned n_slots, unsigned total_paths) {
 
 namespace rtl {
 
-hipError_t set_wavefront_lds_limit(int bytes) {
+// This file is compiled twice: as is, and with -DRT_INST (the two-level traversal of scenes with
+// instances; launchers suffixed _inst), like rt_kernels.hip.
+#if defined(RT_INST)
+#define RT_WF_NAME(x) x##_inst
+#else
+#define RT_WF_NAME(x) x
+#endif
+
+hipError_t RT_WF_NAME(set_wavefront_lds_limit)(int bytes) {
     hipError_t e = hipSuccess;
 #define RT_SETW(TR, L)                                                                                       \
     if (e == hipSuccess)                                                                                     \
@@ -335,7 +346,7 @@ hipError_t set_wavefront_lds_limit(int bytes) {
 // are enqueued eight at a time, and the next eight go out before the host looks at the counters
 // the previous eight left behind, so the GPU never waits for that look; the rounds that turn out
 // to be superfluous find empty queues and end at once.
-hipError_t render_wavefront(const DevScene &sc, const DevCamera &cam, const RenderParams &rp, const WfBuffers &wf,
+hipError_t RT_WF_NAME(render_wavefront)(const DevScene &sc, const DevCamera &cam, const RenderParams &rp, const WfBuffers &wf,
                             unsigned n_slots, const LaunchGeom &lg, unsigned *host_cnt, hipStream_t stream,
                             int *rounds_out) {
     const unsigned total = (unsigned)rp.n_pixels * (unsigned)rp.sample_count;

@@ -37,6 +37,23 @@ def test_instanced_scene_traces_like_the_written_out_one(monkeypatch):
         sc.close()
 
 
+def test_two_level_scene_built_on_the_device():
+    """RT_SCENE_BUILD_DEVICE on a scene with instances: every tree of it (one per distinct sub-scene, one over
+    the loose primitives and the instances' boxes) comes from the device-side builder, and the closest
+    hits are still those of the written-out scene, bit for bit."""
+    B = _binding()
+    scene, written_out, origin = two_level_scene()
+    rays = two_level_rays(200_000)
+    ref, _ = O.OracleScene(written_out).trace(rays, 0.001, np.inf, O.TRACE_REFERENCE)
+    for flags in (abi.RT_SCENE_BUILD_DEVICE, abi.RT_SCENE_BUILD_DEVICE | abi.RT_SCENE_FORCE_GLOBAL):
+        sc = B.Scene(scene, flags=flags)
+        info = sc.info()
+        assert info.built_on_device == 1 and info.n_nodes > 0
+        for sched in (False, True):
+            check_two_level_hits(sc.trace(rays, sched=sched), ref, origin)
+        sc.close()
+
+
 def test_instanced_scene_renders_like_the_written_out_one():
     B = _binding()
     scene, written_out, _ = two_level_scene()
@@ -54,8 +71,9 @@ def test_instanced_scene_renders_like_the_written_out_one():
     # the whole-ray scheduler and a second render of the same thing
     img_c, st_c = a.render(cam, 8, seed=3)
     assert np.array_equal(img_a, img_c) and st_a.rays == st_c.rays
-    with pytest.raises(B.RtError):
-        a.render(cam, 8, seed=3, mode=abi.RT_MODE_WAVEFRONT)  # its hit records carry no instance
+    # the wavefront variant carries the instance of a hit in its path records: the same image
+    img_w, st_w = a.render(cam, 8, seed=3, mode=abi.RT_MODE_WAVEFRONT)
+    assert np.array_equal(img_a, img_w) and st_a.rays == st_w.rays
     a.close()
     b.close()
 
