@@ -224,9 +224,6 @@ struct DevScene {
     // first node on, and the test runs when all lanes of a wave start rays together.
     int n_big;
     int big_quads;
-    // Largest diagonal of a tree leaf's box, in the units of the world-space ray direction (the host
-    // scales it where wrappers change lengths): the absolute part of the culling slack (Trav::cull_t).
-    float cull_len;
     int n_slots;
     int n_nodes;
     int n_textures;
@@ -388,15 +385,18 @@ RT_HD bool sphere_test(f4 g0, f4 g1, f3 o, f3 d, float a, float tm, float tmin, 
 // of a real intersection always pass (their closest point lies inside the sphere); the tree
 // traversal drops the others, so that every hit it reports lies inside its leaf's box up to the
 // rounding that Trav::cull_t allows for.
-RT_HD bool sphere_approach_in_box(f4 g0, f4 g1, f3 o, f3 d, float a, float tm) {
-    f3 center = xyz(g0) + tm * xyz(g1);
-    f3 oc = center - o;
+RT_HD bool sphere_far(f4 g0, f4 g1, f3 o, float tm) {
     // Nearer than 160 radii no such hit exists: the computed discriminant is off by less than
     // 24 * 2^-24 |d|^2 |oc|^2 (19 roundings of terms of that size at most), and a closest approach
     // outside the box below means a true discriminant below -0.038 |d|^2 radius^2.
+    f3 center = xyz(g0) + tm * xyz(g1);
+    f3 oc = center - o;
     float r2 = g0.w * g0.w;
-    float c = len2(oc) - r2;
-    if (!(c > 26000.0f * r2)) return true; // (most waves skip the rest)
+    return (len2(oc) - r2) > 26000.0f * r2;
+}
+RT_HD bool sphere_approach_in_box(f4 g0, f4 g1, f3 o, f3 d, float a, float tm) {
+    f3 center = xyz(g0) + tm * xyz(g1);
+    f3 oc = center - o;
     float h = dot(d, oc);
     // the closest point is o + (h / a) d; its offset from the centre, times a = |d|^2 > 0 (no division)
     f3 off = h * d - a * oc;
@@ -795,12 +795,16 @@ template <typename T, int STRIDE = 0> struct TravStack {
 struct Trav {
     BoxRay br;
     float best_t;
-    // Boxes are culled against cull_t = best_t (1 + RT_CULL_REL) + cull_abs, not against best_t: a box
-    // that is dropped then lies so far beyond the closest hit so far that no primitive inside it can
-    // report a parameter before it, rounding included.  The closest hit is then the closest over ALL
+    // Boxes are culled against cull_t = best_t (1 + RT_CULL_REL), not against best_t: a box that is
+    // dropped then lies so far beyond the closest hit so far that no primitive inside it can report
+    // a parameter before it, rounding included.  The closest hit is then the closest over ALL
     // primitives whose boxes the ray meets, whatever the order and the moment in which leaves are
-    // tested (lanes of the decoupled kernels walk on past leaves they have not tested yet).
-    float cull_t, cull_abs;
+    // tested (lanes of the decoupled kernels walk on past leaves they have not tested yet).  Why
+    // a relative slack is enough: within 16 radii of a sphere the rounding of its root stays below
+    // the 2 % of the radius by which the host grows the sphere's box (a real hit lies that far
+    // behind the box's entry at least), beyond that it stays below RT_CULL_REL of the distance; a
+    // quad's hit point lies inside its (grown) box, so its parameter is never before the entry.
+    float cull_t;
     int best_slot;
     int ref;
     int sp; // entries on the stack, times the stride
@@ -811,22 +815,12 @@ struct Trav {
     f3 io, id;     // inside an instance: the ray in the sub-scene's space (taken there once, on entry)
     float idd;     // ... and |d|^2 there
 };
-RT_HD float rsqrt_approx(float x) { // only feeds slacks: 1 ulp is plenty
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_amdgcn_rsqf(x);
-#else
-    return 1.0f / sqrtf(x);
-#endif
-}
-RT_HD float cull_bound(float best_t, float cull_abs) { return __builtin_fmaf(best_t, 1.0f + RT_CULL_REL, cull_abs); }
-RT_HD void trav_begin(Trav &tv, const Ray &r, float tmax, const DevScene &sc) {
+RT_HD float cull_bound(float best_t) { return best_t * (1.0f + RT_CULL_REL); }
+RT_HD void trav_begin(Trav &tv, const Ray &r, float tmax) {
     tv.br = make_box_ray(r);
     tv.dd = len2(r.d);
     tv.best_t = tmax;
-    // (a direction of length 0 or a non-finite one makes the product inf or NaN: fminf turns both into a
-    // huge finite slack, which culls nothing)
-    tv.cull_abs = fminf(RT_CULL_REL * sc.cull_len * rsqrt_approx(tv.dd), 3.0e38f);
-    tv.cull_t = cull_bound(tmax, tv.cull_abs);
+    tv.cull_t = cull_bound(tmax);
     tv.best_slot = -1;
     tv.best_is_quad = false;
     tv.ref = 0; // root
@@ -1058,7 +1052,8 @@ RT_HD void trav_test_leaf(Trav &tv, int leaf_ref, const DevScene &sc, const Scen
         if constexpr (COUNT) cn.sphh += h ? 1 : 0;
         h = h && t <= tv.best_t;
         // (primitives tested up front are never culled: their hits stand as computed)
-        if (RT_OWN_BOX_RULE && IN_TREE && h) h = sphere_approach_in_box(g[0], g[1], o, d, dd, r.tm);
+        if (RT_OWN_BOX_RULE && IN_TREE && h && sphere_far(g[0], g[1], o, r.tm)) // (rare: most waves skip it)
+            h = sphere_approach_in_box(g[0], g[1], o, d, dd, r.tm);
     } else {
         RT_COUNT(quad);
         h = quad_test(g[0], g[1], g[2], g[3], o, d, tmin, tv.best_t, t);
@@ -1072,7 +1067,7 @@ RT_HD void trav_test_leaf(Trav &tv, int leaf_ref, const DevScene &sc, const Scen
         }
         if (take) {
             tv.best_t = t;
-            tv.cull_t = cull_bound(t, tv.cull_abs);
+            tv.cull_t = cull_bound(t);
             tv.best_slot = s;
             tv.best_is_quad = is_quad;
             if (RT_FEAT_INSTANCE) tv.best_inst = tv.cur_inst;
@@ -1132,7 +1127,7 @@ template <bool COUNT, class ST, bool SPILL = false, int NODE_F4 = RT_NODE_F4>
 RT_HD TraceHit trace_bvh(const DevScene &sc, const SceneView &v, const Ray &r, float tmin, float tmax,
                          const ST &st, Cnt<COUNT> &cn) {
     Trav tv;
-    trav_begin(tv, r, tmax, sc);
+    trav_begin(tv, r, tmax);
     trav_test_big<COUNT>(tv, sc, v, r, tmin, cn);
     while (tv.ref != RT_TRAV_DONE) {
         if (tv.ref >= 0) {

@@ -707,8 +707,6 @@ struct HostScene {
     std::vector<i4> inst;
     // primitives kept out of the tree and tested by every ray up front: slots [0, n_big)
     int n_big = 0, big_quads = 0;
-    // largest diagonal of a tree leaf's box in units of the world-space ray direction (DevScene::cull_len)
-    float cull_len = 0.0f;
 };
 
 // Adds node_base to the inner references of wide nodes [first, first + count) and maps their
@@ -832,41 +830,6 @@ inline int flatten_scene(const rt_scene_desc *d, uint32_t flags, HostScene &out,
         }
     }
 
-    // Culling slack (rt_core.h Trav::cull_t): the error of a primitive's reported parameter scales with
-    // |oc| / |d| in the space the primitive is tested in, and |oc| is at most the distance to its box plus
-    // the box's diagonal.  Wrappers that scale change |d|: by how much at most follows from the scaling
-    // ops of the chains between the world and that space.
-    auto chain_stretch = [&](int c, float &smin, float &smax) { // lengths: world = object * [smin, smax]
-        smin = smax = 1.0f;
-        if (c < 0) return;
-        for (int k = d->chains[c].first_op; k < d->chains[c].first_op + d->chains[c].n_ops; k++)
-            if (d->xform_ops[k].type == RT_XF_SCALE) {
-                float lo = std::fabs(ops[k].p.x), hi = lo;
-                lo = std::min(lo, std::min(std::fabs(ops[k].p.y), std::fabs(ops[k].p.z)));
-                hi = std::max(hi, std::max(std::fabs(ops[k].p.y), std::fabs(ops[k].p.z)));
-                smin *= lo;
-                smax *= hi;
-            }
-    };
-    auto diagonal = [](const Box3 &b) {
-        const float x = b.hi[0] - b.lo[0], y = b.hi[1] - b.lo[1], z = b.hi[2] - b.lo[2];
-        return std::sqrt(x * x + y * y + z * z);
-    };
-    std::vector<float> slack_len(linear ? 0 : n, 0.0f);
-    for (int i = 0; i < n && !linear; i++) {
-        float smin, smax;
-        chain_stretch(d->prims[i].xform, smin, smax);
-        // boxes[i] is in the space outside the primitive's own wrappers
-        const float f = diagonal(boxes[i]) * (smin > 0.0f ? smax / smin : 1.0f);
-        slack_len[i] = std::isfinite(f) ? f : 0.0f;
-    }
-    for (int k = 0; k < d->n_instances; k++) { // a sub-scene's primitives are tested inside the instance's wrappers
-        float smin, smax;
-        chain_stretch(d->instances[k].xform, smin, smax);
-        for (int i = d->instances[k].first_prim; i < d->instances[k].first_prim + d->instances[k].n_prims; i++)
-            if (smax > 1.0f && !linear) slack_len[i] = std::max(slack_len[i], slack_len[i] * smax);
-    }
-
     // Binary tree over a set of boxes: the external (device-side) builder where one is given and it
     // delivers a tree of the expected shape, else the host's binned-SAH builder.
     bool any_external = false, all_external = true;
@@ -970,8 +933,6 @@ inline int flatten_scene(const rt_scene_desc *d, uint32_t flags, HostScene &out,
             if (getenv("RT_AMD_NO_BIG")) big.clear();
             for (int i : big) in_template[i] = 2; // (neither in a sub-scene nor an item of the top tree)
         }
-        for (int i = 0; i < n; i++)
-            if (in_template[i] != 2) out.cull_len = std::max(out.cull_len, slack_len[i]);
         // items of the top tree: the other loose primitives, then the instances
         std::vector<Box3> ib;
         std::vector<int> it, item_prim;
@@ -1076,7 +1037,6 @@ inline int flatten_scene(const rt_scene_desc *d, uint32_t flags, HostScene &out,
                 if (!is_big[i]) rest.push_back(i);
         }
         const int n_big = (int)big.size(), n_rest = (int)rest.size();
-        for (int i : rest) out.cull_len = std::max(out.cull_len, slack_len[i]);
         std::vector<Box3> rest_boxes_store;
         std::vector<int> rest_types_store;
         const std::vector<Box3> *tb = &boxes;

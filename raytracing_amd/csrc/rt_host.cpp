@@ -463,7 +463,6 @@ static int impl_rt_scene_create(const rt_scene_desc *d, int device, uint32_t fla
     dv.n_inst = (int)hs.inst.size();
     dv.n_big = hs.n_big;
     dv.big_quads = hs.big_quads;
-    dv.cull_len = hs.cull_len;
     dv.n_nodes = hs.n_nodes;
     dv.n_top = 0; // chosen with the launch geometry
     s->tree_top = hs.n_top;

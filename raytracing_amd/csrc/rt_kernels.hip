@@ -345,7 +345,7 @@ render_mega_bvh(DevScene sc, DevCamera cam, RenderParams rp) {
         // scattered rays and camera rays set their traversal up together (more lanes per instruction)
         RT_MARK("begin");
         if (begin) {
-            trav_begin(tv, ps.ray, RT_INF, sc);
+            trav_begin(tv, ps.ray, RT_INF);
             trav_test_big<COUNT>(tv, sc, vw, ps.ray, 0.001f, cn);
         }
         RT_TOCK(c_regen);
@@ -584,7 +584,7 @@ trace_sched(DevScene sc, RenderParams rp, const rt_ray *rays, long long n_rays, 
                 ray.o = mk(in.orig[0], in.orig[1], in.orig[2]);
                 ray.d = mk(in.dir[0], in.dir[1], in.dir[2]);
                 ray.tm = in.tm;
-                trav_begin(tv, ray, tmax, sc);
+                trav_begin(tv, ray, tmax);
                 trav_test_big<false>(tv, sc, vw, ray, tmin, cn);
                 pend = Parked();
                 state = ST_TRAV;

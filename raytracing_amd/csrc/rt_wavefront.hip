@@ -206,7 +206,7 @@ wf_trace(DevScene sc, WfBuffers wf, const int *q_trace_cur, RenderParams rp) {
                     ray.o = mk(o.x, o.y, o.z);
                     ray.d = mk(d.x, d.y, d.z);
                     ray.tm = o.w;
-                    trav_begin(tv, ray, RT_INF, sc);
+                    trav_begin(tv, ray, RT_INF);
                     trav_test_big<false>(tv, sc, vw, ray, 0.001f, cn);
                     pend = Parked();
                     state = ST_TRAV;

@@ -56,7 +56,6 @@ void *sim_scene_create(const rt_scene_desc *d, uint32_t flags) {
     dv.n_inst = (int)s->hs.inst.size();
     dv.n_big = s->hs.n_big;
     dv.big_quads = s->hs.big_quads;
-    dv.cull_len = s->hs.cull_len;
     dv.n_nodes = s->hs.n_nodes;
     dv.slot_f4 = s->hs.slot_f4;
     dv.traversal = s->hs.linear ? TRAV_LINEAR : TRAV_BVH;
@@ -181,7 +180,7 @@ int sim_schedule_certificate(void *scene, const rt_ray *rays, long long n, float
         r.d = mk(rays[k].dir[0], rays[k].dir[1], rays[k].dir[2]);
         r.tm = rays[k].tm;
         Trav tv;
-        trav_begin(tv, r, tmax, sc);
+        trav_begin(tv, r, tmax);
         trav_test_big<false>(tv, sc, vw, r, tmin, cn);
         const float up_front_t = tv.best_t; // (tested before the walk in every schedule)
         leaves.clear();
@@ -203,7 +202,7 @@ int sim_schedule_certificate(void *scene, const rt_ray *rays, long long n, float
                 float e;
                 // (culled against the up-front primitives' hit only: every schedule has that one)
                 if (box_hit_planes(px[c], py[c], pz[c], qx[c], qy[c], qz[c], tv.br, tmin,
-                                   cull_bound(up_front_t, tv.cull_abs), e))
+                                   cull_bound(up_front_t), e))
                     todo.push_back(Item{__builtin_bit_cast(int, rf[c]), e > it.pme ? e : it.pme});
             }
         }
@@ -222,11 +221,11 @@ int sim_schedule_certificate(void *scene, const rt_ray *rays, long long n, float
         for (size_t j = 0; j < leaves.size(); j++)
             if (own_t[j] == tv.best_t && tv.best_slot >= sc.n_big) {
                 const float wide = 1.0f + 1.9073486328125e-6f; // (box_hit_planes' own widening)
-                if (!(leaves[j].pme <= __builtin_fmaf(cull_bound(tv.best_t, tv.cull_abs), wide, tv.br.e2))) {
+                if (!(leaves[j].pme <= __builtin_fmaf(cull_bound(tv.best_t), wide, tv.br.e2))) {
                     risky = true;
                     if (getenv("SIM_CERT_DEBUG"))
-                        fprintf(stderr, "ray %lld: t %.9g path-max entry %.9g bound %.9g |d| %.6g cull_abs %.6g slot %d o (%g %g %g) d (%g %g %g)\n",
-                                k, tv.best_t, leaves[j].pme, cull_bound(tv.best_t, tv.cull_abs), sqrtf(tv.dd), tv.cull_abs,
+                        fprintf(stderr, "ray %lld: t %.9g path-max entry %.9g bound %.9g |d| %.6g slot %d o (%g %g %g) d (%g %g %g)\n",
+                                k, tv.best_t, leaves[j].pme, cull_bound(tv.best_t), sqrtf(tv.dd),
                                 tv.best_slot, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z);
                     if (getenv("SIM_CERT_DEBUG")) {
                         const f4 *g = vw.slots + slot_words(sc, tv.best_slot);
