@@ -274,6 +274,59 @@ static void grove() {
     shoot(world, View{kWide, 640, 16, kSky, 35.0f, point3(4.0f, 9.0f, 26.0f), point3(0.0f, 1.0f, 0.0f), 0.0f, 10.0f});
 }
 
+// Sharing on two levels: a tree is a trunk, a dozen fruit and nine placements of one shrub (the
+// shrub of `grove`); forty wrappers place the one tree.  The reference walks tree and shrub through
+// both sets of wrappers; the drop-in records the shrub once and the tree's own primitives once, and
+// places the shrub 360 times under the composed wrappers (RTAMD_INSTANCES=0: 24 000 primitives
+// written out, same image).  No counterpart in main.cpp.
+static void orchard() {
+    uint64_t state = 0x0DDBA11ull;
+    auto u01 = [&]() {
+        uint64_t z = (state += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        return float(z >> 40) * (1.0f / 16777216.0f);
+    };
+    hittable_list shrub;
+    auto leaf = make_shared<lambertian>(color(0.15f, 0.45f, 0.12f));
+    auto shine = make_shared<metal>(color(0.7f, 0.8f, 0.3f), 0.3f);
+    for (int i = 0; i < 48; i++) {
+        float x = 1.2f * (u01() - 0.5f), y = 1.2f * (u01() - 0.5f), z = 1.2f * (u01() - 0.5f), r = 0.08f + 0.16f * u01();
+        shrub.add(make_shared<sphere>(point3(x, y, z), r, i % 9 == 0 ? (shared_ptr<material>)shine : leaf));
+    }
+    shared_ptr<hittable> one_shrub = make_shared<bvh_node>(shrub);
+
+    hittable_list tree;
+    auto bark = make_shared<lambertian>(color(0.35f, 0.25f, 0.15f));
+    tree.add(box(point3(-0.15f, 0.0f, -0.15f), point3(0.15f, 2.2f, 0.15f), bark));
+    auto fruit = make_shared<lambertian>(color(0.8f, 0.15f, 0.1f));
+    auto glass = make_shared<dielectric>(1.5f);
+    for (int i = 0; i < 12; i++) {
+        float ang = 6.2831853f * u01(), rad = 0.5f + 0.9f * u01(), y = 1.4f + 1.6f * u01();
+        tree.add(make_shared<sphere>(point3(rad * std::cos(ang), y, rad * std::sin(ang)), 0.09f, i % 4 == 0 ? (shared_ptr<material>)glass : fruit));
+    }
+    for (int i = 0; i < 9; i++) {
+        float ang = 6.2831853f * (i + 0.5f * u01()) / 9.0f, rad = i == 0 ? 0.0f : 0.9f, y = i == 0 ? 3.0f : 1.9f + 0.9f * u01();
+        float size = 0.8f + 0.5f * u01();
+        shared_ptr<hittable> h = make_shared<rotate_xyz>(one_shrub, 40.0f * u01(), 360.0f * u01(), 40.0f * u01());
+        if (i & 1) h = make_shared<scaling>(h, vec3(size, 0.8f * size, size));
+        tree.add(make_shared<translate>(h, vec3(rad * std::cos(ang), y, rad * std::sin(ang))));
+    }
+    shared_ptr<hittable> one_tree = make_shared<bvh_node>(tree);
+
+    hittable_list world;
+    world.add(make_shared<sphere>(point3(0.0f, -1000.0f, 0.0f), 1000.0f, make_shared<lambertian>(ground_checker())));
+    for (int a = -4; a < 4; a++)
+        for (int b = -3; b < 2; b++) {
+            float jx = u01(), jz = u01(), angle = 360.0f * u01(), size = 0.8f + 0.5f * u01();
+            shared_ptr<hittable> h = make_shared<rotate_y>(one_tree, angle);
+            if ((a + b) & 1) h = make_shared<scaling>(h, vec3(size, size * 1.1f, size));
+            world.add(make_shared<translate>(h, vec3(5.0f * a + 2.0f * jx, 0.0f, 5.0f * b + 2.0f * jz)));
+        }
+    shoot(world, View{kWide, 640, 16, kSky, 35.0f, point3(4.0f, 11.0f, 30.0f), point3(0.0f, 1.5f, -4.0f), 0.0f, 10.0f});
+}
+
 // 10^6 cells on a grid, one sphere or quad per cell, plus the ground: splitmix64 keyed layout,
 // twelve draws per cell whether they are used or not.
 // under_bvh / width 480: the two reduced forms the reference harness records (synth60_list, synth60_bvh).
@@ -341,6 +394,7 @@ int main(int argc, char **argv) {
     else if (s == "cornell_box") cornell_box();
     else if (s == "rotated_in_bvh") rotated_in_bvh();
     else if (s == "grove") grove();
+    else if (s == "orchard") orchard();
     else if (s == "synth1m") synth1m(synth_half, synth_bvh);
     else if (s == "synth60_list") synth1m(60, false, 480);
     else if (s == "synth60_bvh") synth1m(60, true, 480);

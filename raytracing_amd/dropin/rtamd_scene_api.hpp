@@ -275,26 +275,53 @@ class Recorder {
     // keeps one copy and one tree of them.  A first, counting pass over the scene (`counting`) finds
     // them: per object, how often a wrapper reached it and how many primitives it holds; the
     // recording pass gets that table in `shared`.
+    // A shared object may hold shared objects in turn (a tree of shrubs placed many times).  The
+    // library's scenes have two levels, so the hierarchy is flattened where it costs nothing: the
+    // inner object becomes an instance of the world once per placement of the outer one, under the
+    // outer placement's wrappers followed by its own (one chain: the ray passes the same
+    // operations in the same order as in the reference's nested hit() calls).  Primitives are
+    // never written out for that; only the 16-byte instance records multiply.
     bool counting = false;
+    size_t n_counted = 0; // primitives the counting pass has passed, written out
     std::map<const void *, std::pair<int, int>> seen;
     const std::map<const void *, std::pair<int, int>> *shared = nullptr;
-    std::map<const void *, std::pair<int, int>> sub_scenes; // object -> {first_prim, n_prims}
-    std::vector<rt_instance> instances;
-    bool in_sub_scene = false;
+    struct SubScene {
+        std::vector<rt_prim> prims; // its own primitives, in its own space
+        std::vector<rt_group> groups;
+        // shared objects inside it: {object, its wrappers relative to this sub-scene, outermost first}
+        std::vector<std::pair<const void *, std::vector<rt_xform_op>>> children;
+        bool recorded = false;
+        int first_prim = -1; // among all primitives, once desc() has appended it
+    };
+    std::map<const void *, SubScene> sub_scenes;
+    std::vector<const void *> sub_order;   // in the order of their first visit
+    std::vector<SubScene *> recording;      // the sub-scenes being recorded, innermost last
+    struct Placement {
+        const void *object;
+        int chain;
+    };
+    std::vector<Placement> placements;
+    std::vector<rt_instance> instances; // filled by desc()
     static const int kMinInstancePrims = 8; // smaller objects are cheaper written out
 
     // Called by a wrapper for the object it holds, with its own op already on open_wrappers.
     template <class F> void child(const void *obj, F record_it) {
         if (counting) {
-            std::pair<int, int> &c = seen[obj];
-            c.first++;
-            const size_t before = prims.size();
+            // (an object is walked on its first visit only, so the pass costs what the hierarchy
+            // holds, not what it expands to)
+            auto it = seen.find(obj);
+            if (it != seen.end()) {
+                it->second.first++;
+                n_counted += (size_t)it->second.second;
+                return;
+            }
+            const size_t before = n_counted;
             record_it();
-            c.second = (int)(prims.size() - before);
+            seen[obj] = std::make_pair(1, (int)(n_counted - before));
             return;
         }
         const std::pair<int, int> *c = nullptr;
-        if (shared && !in_sub_scene) {
+        if (shared) {
             auto it = shared->find(obj);
             if (it != shared->end() && it->second.first >= 2 && it->second.second >= kMinInstancePrims) c = &it->second;
         }
@@ -302,24 +329,37 @@ class Recorder {
             record_it();
             return;
         }
-        auto t = sub_scenes.find(obj);
-        if (t == sub_scenes.end()) { // first visit: its primitives, in its own space
+        SubScene &sub = sub_scenes[obj];
+        if (!sub.recorded) { // first visit: its primitives, in its own space, into its own arrays
+            sub.recorded = true;
+            sub_order.push_back(obj);
             std::vector<rt_xform_op> outer;
             outer.swap(open_wrappers);
             const int outer_depth = bvh_depth;
             bvh_depth = 0;
             bvh_closed = true;
-            in_sub_scene = true;
-            const int first = (int)prims.size();
+            recording.push_back(&sub);
             record_it();
-            in_sub_scene = false;
+            recording.pop_back();
             bvh_depth = outer_depth;
             bvh_closed = true;
             open_wrappers.swap(outer);
-            t = sub_scenes.emplace(obj, std::make_pair(first, (int)prims.size() - first)).first;
         }
-        rt_instance in = {t->second.first, t->second.second, current_chain(), 0};
-        instances.push_back(in);
+        if (recording.empty())
+            place(obj, open_wrappers);
+        else // inside another shared object: placed with every placement of that one
+            recording.back()->children.emplace_back(obj, open_wrappers);
+    }
+    // An instance of the world for `obj` under `wrappers` (outermost first), and one for every shared
+    // object inside it under the wrappers of both.
+    void place(const void *obj, const std::vector<rt_xform_op> &wrappers) {
+        const SubScene &sub = sub_scenes[obj];
+        if (!sub.prims.empty()) placements.push_back(Placement{obj, chain_of(wrappers)});
+        for (const auto &ch : sub.children) {
+            std::vector<rt_xform_op> w(wrappers);
+            w.insert(w.end(), ch.second.begin(), ch.second.end());
+            place(ch.first, w);
+        }
     }
     bool any_shared() const {
         for (const auto &kv : seen)
@@ -327,9 +367,10 @@ class Recorder {
         return false;
     }
 
-    int current_chain() {
-        if (open_wrappers.empty()) return -1;
-        std::vector<rt_xform_op> inner_first(open_wrappers.rbegin(), open_wrappers.rend());
+    int current_chain() { return chain_of(open_wrappers); }
+    int chain_of(const std::vector<rt_xform_op> &outer_first) {
+        if (outer_first.empty()) return -1;
+        std::vector<rt_xform_op> inner_first(outer_first.rbegin(), outer_first.rend());
         std::string key((const char *)inner_first.data(), inner_first.size() * sizeof(rt_xform_op));
         auto it = chain_ids.find(key);
         if (it != chain_ids.end()) return it->second;
@@ -339,15 +380,22 @@ class Recorder {
         return chain_ids[key] = (int)chains.size() - 1;
     }
     void add_prim(rt_prim p) {
+        if (counting) {
+            n_counted++;
+            return;
+        }
         p.xform = current_chain();
+        // (a shared object's primitives go to its own arrays while it is being recorded)
+        std::vector<rt_prim> &pr = recording.empty() ? prims : recording.back()->prims;
+        std::vector<rt_group> &gr = recording.empty() ? groups : recording.back()->groups;
         int kind = bvh_depth > 0 ? RT_GROUP_BVH : RT_GROUP_LIST;
-        if (groups.empty() || groups.back().kind != kind || (kind == RT_GROUP_BVH && bvh_closed)) {
-            rt_group g = {kind, (int32_t)prims.size(), 0, 0};
-            groups.push_back(g);
+        if (gr.empty() || gr.back().kind != kind || (kind == RT_GROUP_BVH && bvh_closed)) {
+            rt_group g = {kind, (int32_t)pr.size(), 0, 0};
+            gr.push_back(g);
             bvh_closed = false;
         }
-        groups.back().n_prims++;
-        prims.push_back(p);
+        gr.back().n_prims++;
+        pr.push_back(p);
     }
     void begin_bvh() {
         if (bvh_depth++ == 0) bvh_closed = true; // the next leaf opens a fresh BVH group
@@ -355,7 +403,25 @@ class Recorder {
     void end_bvh() {
         if (--bvh_depth == 0) bvh_closed = true;
     }
-    rt_scene_desc desc() const {
+    // (appends the sub-scenes to the world's primitives, once, and resolves the placements)
+    rt_scene_desc desc() {
+        if (!finalized) {
+            finalized = true;
+            for (const void *obj : sub_order) {
+                SubScene &sub = sub_scenes[obj];
+                sub.first_prim = (int)prims.size();
+                for (rt_group g : sub.groups) {
+                    g.first_prim += sub.first_prim;
+                    groups.push_back(g);
+                }
+                prims.insert(prims.end(), sub.prims.begin(), sub.prims.end());
+            }
+            for (const Placement &pl : placements) {
+                const SubScene &sub = sub_scenes[pl.object];
+                rt_instance in = {sub.first_prim, (int32_t)sub.prims.size(), pl.chain, 0};
+                instances.push_back(in);
+            }
+        }
         rt_scene_desc d;
         memset(&d, 0, sizeof(d));
         d.abi_version = RT_AMD_ABI_VERSION;
@@ -384,6 +450,7 @@ class Recorder {
 
   private:
     bool bvh_closed = true;
+    bool finalized = false;
 };
 
 // Minimal PNG writer (8-bit RGB, stored deflate blocks): what camera::render needs to put its

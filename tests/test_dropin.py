@@ -244,6 +244,55 @@ def test_shared_objects_become_instances(tmp_path):
         assert np.array_equal(hits[f][m], ref[f][m]), f
 
 
+def test_shared_objects_inside_shared_objects(tmp_path):
+    """Sharing on two levels (examples/scenes.cpp orchard: one shrub placed nine times in a tree,
+    the one tree placed forty times): the shrub and the tree's own primitives are recorded once
+    each, and every shrub of every tree is one rt_instance under the tree's wrappers followed by
+    its own.  The kernels' traversal over that scene against the oracle's scan of the scene with
+    all 18 001 primitives written out (RTAMD_INSTANCES=0): the same primitive, t, p, normal and
+    face, bit for bit."""
+    from tests import sim_lib as S
+    a, b, origin_of, rays = _orchard(tmp_path)
+    ref, _ = O.OracleScene(b).trace(rays, 0.001, np.inf, O.TRACE_REFERENCE)
+    hits, _, _ = S.SimScene(a).trace(rays)
+    _check_orchard_hits(hits, ref, origin_of)
+
+
+def _orchard(tmp_path, n=20_000):
+    _ensure_built()
+    inst, flat = str(tmp_path / "orchard.rtscene"), str(tmp_path / "orchard_flat.rtscene")
+    subprocess.run([RT_SCENES, "orchard", "--dump", inst], check=True, capture_output=True)
+    subprocess.run([RT_SCENES, "orchard", "--dump", flat], check=True, capture_output=True,
+                   env=dict(os.environ, RTAMD_INSTANCES="0"))
+    a, b = abi.SceneArrays.load(inst), abi.SceneArrays.load(flat)
+    assert len(a.prims) == 1 + 18 + 48 and len(a.instances) == 40 * (1 + 9)
+    assert len(b.prims) == 1 + 40 * (18 + 9 * 48) and len(b.instances) == 0
+    n_of = {int(f): int(k) for f, k in zip(a.instances["first_prim"], a.instances["n_prims"])}
+    assert n_of == {1: 18, 19: 48}
+    # a written-out primitive and the recorded one it is a copy of hold the same numbers, in the
+    # object's own space; only the chain differs
+    def key(p):
+        return (int(p["type"]), int(p["material"]), p["a"].tobytes(), p["b"].tobytes(), p["c"].tobytes(), p["d"].tobytes())
+    recorded = {key(p): i for i, p in enumerate(a.prims)}
+    assert len(recorded) == len(a.prims)
+    origin_of = np.array([recorded[key(p)] for p in b.prims])
+    rng = np.random.default_rng(4)
+    rays = np.zeros(n, abi.RAY_DT)
+    rays["orig"] = rng.uniform(-1, 1, (n, 3)) * (24, 5, 16) + (0, 7, -2)
+    rays["dir"] = rng.uniform(-1, 1, (n, 3)) * (22, 2.2, 14) + (0, 2.2, -4) - rays["orig"]
+    return a, b, origin_of, rays
+
+
+def _check_orchard_hits(hits, ref, origin_of):
+    m = ref["prim"] >= 0
+    in_shrub = origin_of[ref["prim"][m]] >= 19
+    assert m.mean() > 0.5 and in_shrub.mean() > 0.15 and ((origin_of[ref["prim"][m]] >= 1) & ~in_shrub).mean() > 0.01
+    assert np.array_equal(hits["prim"] >= 0, m)
+    assert np.array_equal(hits["prim"][m], origin_of[ref["prim"][m]])
+    for f in ("t", "p", "normal", "front_face"):
+        assert np.array_equal(hits[f][m], ref[f][m]), f
+
+
 def test_host_side_materials_and_textures(tmp_path):
     """material::scatter / emitted and texture::value on the host (material.h:13-20, texture.h:13):
     tests/host_virtuals.cpp checks them against closed forms and against the oracle-independent
@@ -326,6 +375,29 @@ def test_shared_objects_render_the_same_as_instances_and_written_out(tmp_path):
         r = subprocess.run([RT_SCENES, "grove", "--spp", "8", "--width", "400", "--out", png], check=True,
                            capture_output=True, env=dict(os.environ, **env))
         assert b"Render took" in r.stderr
+        imgs.append(np.asarray(Image.open(png).convert("RGB")).astype(int))
+    assert imgs[0].std() > 10
+    assert (imgs[0] != imgs[1]).any(axis=2).mean() < 1e-3
+
+
+@pytest.mark.gpu
+def test_shared_objects_inside_shared_objects_on_the_gpu(tmp_path):
+    """The orchard scene (a shared shrub inside a shared tree, 400 instances of 67 primitives) on
+    the GPU: both batch kernels against the oracle's scan of the written-out scene, bit for bit, and
+    camera::render of the drop-in against the render with every copy written out."""
+    from PIL import Image
+    from raytracing_amd import binding
+    a, b, origin_of, rays = _orchard(tmp_path, 60_000)
+    ref, _ = O.OracleScene(b).trace(rays, 0.001, np.inf, O.TRACE_REFERENCE)
+    sc = binding.Scene(a)
+    for sched in (False, True):
+        _check_orchard_hits(sc.trace(rays, sched=sched), ref, origin_of)
+    sc.close()
+    imgs = []
+    for env in ({}, {"RTAMD_INSTANCES": "0"}):
+        png = str(tmp_path / f"orchard{len(imgs)}.png")
+        subprocess.run([RT_SCENES, "orchard", "--spp", "8", "--width", "400", "--out", png], check=True,
+                       capture_output=True, env=dict(os.environ, **env))
         imgs.append(np.asarray(Image.open(png).convert("RGB")).astype(int))
     assert imgs[0].std() > 10
     assert (imgs[0] != imgs[1]).any(axis=2).mean() < 1e-3
