@@ -159,7 +159,10 @@ int validate(const rt_scene_desc *d) {
 // Bytes of LDS the staged arrays take: slots, nodes, both per-slot records, textures
 // (the latter padded to 16 bytes).  Must match the kernels' staging order.
 size_t scene_lds_bytes(const rtc::DevScene &dv) {
-    size_t words = (size_t)dv.n_slots * dv.slot_f4 + (size_t)dv.n_nodes * RT_NODE_LDS_F4 + (size_t)dv.n_slots * 2;
+    size_t words = (size_t)dv.n_slots * dv.slot_f4 + (size_t)dv.n_nodes * RT_NODE_LDS_F4;
+#ifndef RT_REC_GLOBAL
+    words += (size_t)dv.n_slots * 2;
+#endif
     size_t tex = ((size_t)dv.n_textures * sizeof(rt_texture) + 15) / 16;
     return (words + tex) * sizeof(f4);
 }
@@ -186,7 +189,7 @@ LaunchGeom choose_geom(rt_scene *s, uint32_t flags) {
     const int cap = bvh ? RT_STACK_CAP(s->info.bvh_depth) : 0; // stack entries a ray can need
 
     const size_t all_bytes = scene_lds_bytes(dv);
-    const int block = std::max(64, std::min(1024, env_int("RT_AMD_BLOCK", 1024) / 64 * 64));
+    const int block = std::max(64, std::min(RT_MEGA_MAX_THREADS, env_int("RT_AMD_BLOCK", RT_MEGA_MAX_THREADS) / 64 * 64));
     const int threads_per_cu = rtl::mega_waves_per_simd() * 256;
     const int bpc_target = std::max(1, env_int("RT_AMD_BLOCKS_PER_CU", threads_per_cu / block));
     // 16-bit stack entries (instances and the mark that ends a visit to one are leaf "slots" too)

@@ -5,7 +5,9 @@
 
 #include "rt_core.h"
 
-#define RT_MEGA_MAX_THREADS 1024
+#ifndef RT_MEGA_MAX_THREADS
+#define RT_MEGA_MAX_THREADS 1024 // lanes of a workgroup of the persistent render kernels (experiments: 512 ... 1024)
+#endif
 #ifndef RT_MEGA_WAVES_PER_SIMD
 #define RT_MEGA_WAVES_PER_SIMD 4
 #endif

@@ -33,12 +33,14 @@ __device__ __forceinline__ f4 *stage_scene(const DevScene &sc, f4 *smem, SceneVi
     p += n_node_words;
     // (unconditionally: the host only picks the LDS variants when all of this fits, and pointers that
     // are LDS on every path let the compiler use LDS instructions for the records)
+#ifndef RT_REC_GLOBAL // (experiment builds: the records stay in global memory, which halves the LDS copy's size)
     stage_to_lds(p, reinterpret_cast<const f4 *>(sc.rec_i), sc.n_slots);
     v.rec_i = reinterpret_cast<const i4 *>(p);
     p += sc.n_slots;
     stage_to_lds(p, sc.rec_f, sc.n_slots);
     v.rec_f = p;
     p += sc.n_slots;
+#endif
     // the device copy of the texture table is padded to whole 16-byte words
     stage_to_lds(p, reinterpret_cast<const f4 *>(sc.textures), n_tex_words);
     v.textures = reinterpret_cast<const rt_texture *>(p);
