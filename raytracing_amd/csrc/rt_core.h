@@ -1426,16 +1426,25 @@ RT_HD PathState path_start(const DevCamera &cam, uint32_t seed, unsigned pixel, 
 // The part of a ray_color segment that follows the closest-hit query: miss ->
 // background (camera.h:148-161), otherwise emission / scatter (camera.h:164-173).
 // Returns true while the path continues (ps.ray then holds the scattered ray).
+// (the two halves are also called on their own by the kernel that settles misses at once and lets
+// hits wait for company)
+RT_HD void path_missed(const DevCamera &cam, PathState &ps) {
+    ps.L = sh_madd3(ps.beta, mk(cam.background[0], cam.background[1], cam.background[2]), ps.L);
+}
+template <bool COUNT>
+RT_HD bool path_after_hit(const DevScene &sc, const SceneView &vw, PathState &ps, TraceHit h, Cnt<COUNT> &cn) {
+    Surf s = surface_at<false>(sc, vw, ps.ray, h);
+    ps.depth--;
+    return shade_hit<COUNT>(sc, vw, h.slot, ps, s, cn) && ps.depth > 0; // depth 0: camera.h:141 returns black
+}
 template <bool COUNT>
 RT_HD bool path_after_trace(const DevScene &sc, const SceneView &vw, const DevCamera &cam, PathState &ps,
                             TraceHit h, Cnt<COUNT> &cn) {
     if (h.slot < 0) {
-        ps.L = sh_madd3(ps.beta, mk(cam.background[0], cam.background[1], cam.background[2]), ps.L);
+        path_missed(cam, ps);
         return false;
     }
-    Surf s = surface_at<false>(sc, vw, ps.ray, h);
-    ps.depth--;
-    return shade_hit<COUNT>(sc, vw, h.slot, ps, s, cn) && ps.depth > 0; // depth 0: camera.h:141 returns black
+    return path_after_hit<COUNT>(sc, vw, ps, h, cn);
 }
 
 // One whole segment of ray_color: trace, then miss / emit / scatter.  Returns true

@@ -120,6 +120,7 @@ struct rt_scene {
     int n_cu = 256;
     int tree_top = 0; // HostScene::n_top: how many leading nodes are the most visited ones
     bool lean = false; // no quads, no noise / image textures: the lean render kernels apply
+    bool noise = false; // some material reaches a noise texture (shading then costs far more than a short scan)
     LaunchGeom geom; // persistent render kernel: grid, block, LDS bytes, what is staged
     // wavefront variant: path-state arrays and queues (allocated on first use)
     void *wf_mem = nullptr;
@@ -271,6 +272,10 @@ LaunchGeom choose_geom(rt_scene *s, uint32_t flags) {
     // (textured) spheres, which keep the 4-wave build
     lg.dense = !bvh && bpc == 1 && lg.block == 1024 && (s->info.n_spheres == 0 || dv.n_slots >= 8) &&
                env_int("RT_AMD_DENSE", 1) != 0 && dv.n_slots > 0;
+    // scanned scenes with noise textures: hits wait until 48 lanes have one (measured on the reference's
+    // two: +31 % and +9 %; scenes with cheap shading lose 5-15 % to the extra passes of the loop and
+    // keep shading every iteration)
+    lg.shade_min = !bvh && !lg.dense && s->noise ? 48 : 1;
     dv.stack_cap = cap;
     used = (used + 15) / 16 * 16;
     lg.ring_f4 = (int)(used / sizeof(f4));
@@ -423,7 +428,10 @@ static int impl_rt_scene_create(const rt_scene_desc *d, int device, uint32_t fla
     s->info.n_quads = hs.n_quads;
     s->lean = hs.n_quads == 0 && !hs.any_chain && !env_int("RT_AMD_NO_LEAN", 0);
     for (const rt_texture &t : hs.textures) // the table holds only what a material can reach
-        if (t.type == RT_TEX_NOISE || t.type == RT_TEX_IMAGE) s->lean = false;
+        if (t.type == RT_TEX_NOISE || t.type == RT_TEX_IMAGE) {
+            s->lean = false;
+            s->noise = s->noise || t.type == RT_TEX_NOISE;
+        }
     s->info.n_nodes = hs.n_nodes;
     s->info.bvh_depth = hs.bvh_depth;
     s->info.build_ms = (float)build_ms;
@@ -575,7 +583,7 @@ int ensure_wavefront(rt_scene *s, unsigned n_slots) {
 // Knobs of the render kernels' scheduling, read from the environment once per call.
 struct Tunables {
     int scheduler, pipeline, sets, unit_order, strip_order;
-    int min_ready, leaf_min, blocked_min, regen_min;
+    int min_ready, leaf_min, blocked_min, regen_min, shade_min;
     bool timeline;
 };
 Tunables read_tunables(bool lds_scene) {
@@ -589,6 +597,7 @@ Tunables read_tunables(bool lds_scene) {
     t.leaf_min = std::max(1, std::min(64, env_int("RT_AMD_LEAF_MIN", 8)));
     t.blocked_min = std::max(1, std::min(64, env_int("RT_AMD_BLOCKED_MIN", 2)));
     t.regen_min = std::max(1, std::min(64, env_int("RT_AMD_REGEN_MIN", 1)));
+    t.shade_min = std::max(0, std::min(64, env_int("RT_AMD_SHADE_MIN", 0))); // 0: the scene's own (LaunchGeom)
     t.timeline = getenv("RT_AMD_TIMELINE") != nullptr;
     return t;
 }
@@ -616,6 +625,7 @@ RenderParams base_params(int W, int H, int n_pixels, const rt_render_opts *opts,
     rp.leaf_min = tn.leaf_min;
     rp.blocked_min = tn.blocked_min;
     rp.regen_min = tn.regen_min;
+    rp.shade_min = tn.shade_min > 0 ? tn.shade_min : lg.shade_min;
     return rp;
 }
 

@@ -49,7 +49,9 @@ namespace {
 // per scalar load and branch that it is bound by each wave's own instruction latency: the build
 // for 8 waves per SIMD (64 registers; some shading code spills) is 1.2-1.3x faster there, and
 // slower on scenes of a few textured spheres, where the spills cost more than the occupancy gives.
-template <int TRAV, bool LDS_SCENE, bool COUNT, bool RING, int WPS = RT_MEGA_WAVES_PER_SIMD>
+// WAIT: a miss ends its path at once, and hits are shaded together once rp.shade_min of them wait (scenes
+// whose shading costs far more than their scan: noise textures).
+template <int TRAV, bool LDS_SCENE, bool COUNT, bool RING, int WPS = RT_MEGA_WAVES_PER_SIMD, bool WAIT = false>
 __global__ void __launch_bounds__(RT_MEGA_MAX_THREADS, WPS)
 render_mega(DevScene sc, DevCamera cam, RenderParams rp) {
     extern __shared__ f4 smem[];
@@ -70,7 +72,11 @@ render_mega(DevScene sc, DevCamera cam, RenderParams rp) {
     const unsigned long long lane_mask_lt = (1ull << lane) - 1ull;
     WavePool wp;
     pool_init(wp);
-    bool alive = false;
+    bool alive = false, pending = false; // pending: the ray's closest hit is known and waits to be shaded
+    TraceHit h;
+    h.slot = -1;
+    h.t = 0.0f;
+    const int shade_min = rp.shade_min;
     PathState ps;
     unsigned pixel = 0, sample = 0, n_rays = 0;
     Cnt<COUNT> cn;
@@ -134,25 +140,80 @@ render_mega(DevScene sc, DevCamera cam, RenderParams rp) {
             if (wp.exhausted && wp.k >= wp.k_end) break;
             continue;
         }
-        if (alive) {
-            bool cont;
-            if constexpr (COUNT) {
-                // instrumented variant: split the segment to time trace and shade separately
-                long long c0 = clock64();
-                cont = false;
-                TraceHit h;
-                h.slot = -1;
-                h.t = 0.0f;
-                bool go = ps.depth > 0;
-                if (go) {
+        if constexpr (!WAIT) {
+            if (alive) {
+                bool cont;
+                if constexpr (COUNT) {
+                    // instrumented variant: split the segment to time trace and shade separately
+                    long long c0 = clock64();
+                    cont = false;
+                    TraceHit h;
+                    h.slot = -1;
+                    h.t = 0.0f;
+                    bool go = ps.depth > 0;
+                    if (go) {
+                        n_rays++;
+                        if constexpr (TRAV == TRAV_LINEAR)
+                            h = trace_linear<COUNT>(sc, vw, ps.ray, 0.001f, RT_INF, cn);
+                        else
+                            h = trace_bvh<COUNT, Stack, SPILL, LDS_SCENE ? RT_NODE_LDS_F4 : RT_NODE_F4>(sc, vw, ps.ray, 0.001f, RT_INF, st, cn);
+                    }
+                    long long c1 = clock64();
+                    if (go) cont = path_after_trace<COUNT>(sc, vw, cam, ps, h, cn);
+                    long long c2 = clock64();
+                    if (lane == __builtin_ctzll(__ballot(true))) {
+                        w_cycles[1] += c1 - c0;
+                        w_cycles[2] += c2 - c1;
+                        w_cycles[3] += 1;
+                        w_cycles[4] += __popcll(__ballot(true));
+                    }
+                } else {
+                    cont = path_step<TRAV, COUNT, Stack, SPILL, LDS_SCENE ? RT_NODE_LDS_F4 : RT_NODE_F4>(sc, vw, cam, ps, st, n_rays, cn);
+                }
+                if (!cont) {
+                    write_record(rp, sample, pixel, ps.L, n_rays);
+                    alive = false;
+                }
+            }
+        } else {
+            // ---- closest hits of the lanes whose ray has none yet -----------------------------------
+            long long c0 = COUNT ? clock64() : 0;
+            if (alive && !pending) {
+                if (ps.depth <= 0) { // camera.h:141
+                    write_record(rp, sample, pixel, ps.L, n_rays);
+                    alive = false;
+                } else {
                     n_rays++;
                     if constexpr (TRAV == TRAV_LINEAR)
                         h = trace_linear<COUNT>(sc, vw, ps.ray, 0.001f, RT_INF, cn);
                     else
                         h = trace_bvh<COUNT, Stack, SPILL, LDS_SCENE ? RT_NODE_LDS_F4 : RT_NODE_F4>(sc, vw, ps.ray, 0.001f, RT_INF, st, cn);
+                    pending = true;
                 }
-                long long c1 = clock64();
-                if (go) cont = path_after_trace<COUNT>(sc, vw, cam, ps, h, cn);
+            }
+            long long c1 = COUNT ? clock64() : 0;
+            // ---- a miss ends its path at once (camera.h:148-161) ------------------------------------
+            if (pending && h.slot < 0) {
+                path_missed(cam, ps);
+                write_record(rp, sample, pixel, ps.L, n_rays);
+                alive = false;
+                pending = false;
+            }
+            // ---- hits are shaded together: when shade_min of them wait, when every lane has one, or
+            // when no new paths are left to start in the lanes that have none (a scene whose shading is
+            // expensive next to its scan - noise textures - then shades with most lanes, and scans for
+            // the few that missed in between; shade_min = 1 shades in every iteration)
+            const unsigned long long hits = __ballot(pending);
+            if (hits != 0ull && (__popcll(hits) >= shade_min || !__any(!alive) || (wp.exhausted && wp.k >= wp.k_end))) {
+                if (pending) {
+                    pending = false;
+                    if (!path_after_hit<COUNT>(sc, vw, ps, h, cn)) {
+                        write_record(rp, sample, pixel, ps.L, n_rays);
+                        alive = false;
+                    }
+                }
+            }
+            if constexpr (COUNT) {
                 long long c2 = clock64();
                 if (lane == __builtin_ctzll(__ballot(true))) {
                     w_cycles[1] += c1 - c0;
@@ -160,12 +221,6 @@ render_mega(DevScene sc, DevCamera cam, RenderParams rp) {
                     w_cycles[3] += 1;
                     w_cycles[4] += __popcll(__ballot(true));
                 }
-            } else {
-                cont = path_step<TRAV, COUNT, Stack, SPILL, LDS_SCENE ? RT_NODE_LDS_F4 : RT_NODE_F4>(sc, vw, cam, ps, st, n_rays, cn);
-            }
-            if (!cont) {
-                write_record(rp, sample, pixel, ps.L, n_rays);
-                alive = false;
             }
         }
         if constexpr (COUNT) {
@@ -620,6 +675,9 @@ static hipError_t launch_mega_tcr(const DevScene &sc, const DevCamera &cam, cons
     else if (TRAV == TRAV_LINEAR && lg.dense)
         hipLaunchKernelGGL((render_mega<TRAV, LDS_SCENE, false, RING, TRAV == TRAV_LINEAR ? 8 : RT_MEGA_WAVES_PER_SIMD>),
                            dim3(lg.grid), dim3(lg.block), lg.lds_bytes, stream, sc, cam, rp);
+    else if (TRAV == TRAV_LINEAR && rp.shade_min > 1)
+        hipLaunchKernelGGL((render_mega<TRAV, LDS_SCENE, false, RING, RT_MEGA_WAVES_PER_SIMD, TRAV == TRAV_LINEAR>),
+                           dim3(lg.grid), dim3(lg.block), lg.lds_bytes, stream, sc, cam, rp);
     else
         hipLaunchKernelGGL((render_mega<TRAV, LDS_SCENE, false, RING>), dim3(lg.grid), dim3(lg.block), lg.lds_bytes,
                            stream, sc, cam, rp);
@@ -701,6 +759,15 @@ hipError_t RT_LAUNCH_NAME(set_mega_lds_limit)(int bytes) {
     RT_SET8(false, true)
     RT_SET8(false, false)
 #undef RT_SET8
+#define RT_SETW(L, R)                                                                                        \
+    if (e == hipSuccess)                                                                                     \
+        e = hipFuncSetAttribute((const void *)render_mega<TRAV_LINEAR, L, false, R, RT_MEGA_WAVES_PER_SIMD, true>, \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    RT_SETW(true, true)
+    RT_SETW(true, false)
+    RT_SETW(false, true)
+    RT_SETW(false, false)
+#undef RT_SETW
     RT_SET(TRAV_LINEAR, true, true)
     RT_SET(TRAV_LINEAR, true, false)
     RT_SET(TRAV_LINEAR, false, true)

@@ -47,6 +47,7 @@ struct RenderParams {
     int leaf_min;  // decoupled: lanes that must hold a parked leaf before the leaf block runs
     int blocked_min; // decoupled: ... or this many lanes stalled on a second leaf
     int regen_min;   // decoupled: idle lanes that must accumulate before new paths are started
+    int shade_min;   // whole-ray kernels: hits that must wait before they are shaded (1: every iteration)
     // Debugging aid (non-null): every wave of the decoupled kernel leaves {start, out of new
     // paths, exit} in 100 MHz wall-clock ticks and its hardware id, 4 x 8 bytes per wave.
     unsigned long long *timeline;
@@ -67,6 +68,7 @@ struct LaunchGeom {
     // linear scenes that are mostly scan: the kernel built for 8 waves per SIMD.  Pipelined launches
     // keep one workgroup per CU each (two launches share a CU); a launch on its own starts two.
     bool dense = false;
+    int shade_min = 1; // whole-ray kernels: hits that wait before they are shaded together (RenderParams::shade_min)
     // scenes read from HBM: the waves read their nodes together through per-wave staging areas in LDS
     // (rt_sched.h coop_fetch_nodes); the tree's top is then not cached in LDS
     bool coop = false;
