@@ -315,7 +315,10 @@ int rt_render(rt_scene *scene, const rt_camera_desc *cam, const rt_render_opts *
 /* accum lives in device memory; kernels are enqueued on `stream`.  With
  * stats == NULL the megakernel call does not synchronise (RT_MODE_WAVEFRONT polls its
  * queue counters and does).  A scene owns the per-launch scratch (path records, queues), so
- * calls on one scene must be ordered: one stream at a time. */
+ * calls on one scene must be ordered: one stream at a time.  That scratch is up to three sets of
+ * per-path records (16 bytes x samples x pixels of one launch each, a set bounded by the
+ * environment's RT_AMD_STAGE_MB, default 2048 MB: larger sample counts are split into launches);
+ * sets are allocated when a call first needs them and released by rt_scene_destroy. */
 int rt_render_device(rt_scene *scene, const rt_camera_desc *cam, const rt_render_opts *opts,
                      float *d_accum, void *stream, rt_render_stats *stats);
 
