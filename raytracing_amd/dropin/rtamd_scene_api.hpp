@@ -12,6 +12,7 @@
 
 #include "rtamd_jpeg.hpp"
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdint>
@@ -22,8 +23,10 @@
 #include <limits>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <random>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rt_amd.h"
@@ -267,7 +270,14 @@ class Recorder {
     std::vector<rt_xform_op> ops;
     std::vector<rt_xform_chain> chains;
     std::vector<rt_xform_op> open_wrappers; // outermost first
-    std::map<const void *, int> material_ids, texture_ids;
+    // Every recorder has a number of its own: materials and textures remember the index they got
+    // from the recorder of that number (a large scene has 10^6 of each; a table from object to
+    // index would be searched three times per primitive).
+    const uint64_t serial = next_serial();
+    static uint64_t next_serial() {
+        static std::atomic<uint64_t> n{0};
+        return ++n;
+    }
     std::map<std::string, int> chain_ids;
     int bvh_depth = 0; // > 0 while recording the leaves of a bvh_node
     // Objects that several instance wrappers hold (hittable.h:51-344 keep a shared_ptr to what they
@@ -712,11 +722,19 @@ class texture {
 
   protected:
     int memo(rtamd::Recorder &r, const rt_texture &t) const {
-        auto it = r.texture_ids.find(this);
-        if (it != r.texture_ids.end()) return it->second;
+        int id;
+        if (known(r, id)) return id;
         r.textures.push_back(t);
-        return r.texture_ids[this] = (int)r.textures.size() - 1;
+        recorded_by = r.serial;
+        return recorded_as = (int)r.textures.size() - 1;
     }
+    bool known(const rtamd::Recorder &r, int &id) const {
+        if (recorded_by != r.serial) return false;
+        id = recorded_as;
+        return true;
+    }
+    mutable uint64_t recorded_by = 0; // the recorder (Recorder::serial) that holds this texture ...
+    mutable int recorded_as = -1;     // ... at this index
     static rt_texture blank(int type) {
         rt_texture t;
         memset(&t, 0, sizeof(t));
@@ -753,8 +771,8 @@ class checker_texture : public texture {
         return (cell % 2 == 0 ? even : odd)->value(u, v, p);
     }
     int record(rtamd::Recorder &r) const override {
-        auto it = r.texture_ids.find(this);
-        if (it != r.texture_ids.end()) return it->second;
+        int known_id;
+        if (known(r, known_id)) return known_id;
         rt_texture t = blank(RT_TEX_CHECKER);
         t.scale = inv_scale;
         t.even = even->record(r);
@@ -782,8 +800,8 @@ class image_texture : public texture {
         return color(cs * px[0], cs * px[1], cs * px[2]);
     }
     int record(rtamd::Recorder &r) const override {
-        auto it = r.texture_ids.find(this);
-        if (it != r.texture_ids.end()) return it->second;
+        int known_id;
+        if (known(r, known_id)) return known_id;
         rt_texture t = blank(RT_TEX_IMAGE);
         if (image.height() > 0) { // a missing file renders as (0,0,1): texture.h:62
             rt_image im = {image.width(), image.height(), (uint64_t)r.texels.size()};
@@ -805,8 +823,8 @@ class noise_texture : public texture {
         return color(0.5f, 0.5f, 0.5f) * (1.0f + sinf(scale * p.z() + 10.0f * noise.turb(p, 7)));
     }
     int record(rtamd::Recorder &r) const override {
-        auto it = r.texture_ids.find(this);
-        if (it != r.texture_ids.end()) return it->second;
+        int known_id;
+        if (known(r, known_id)) return known_id;
         rt_texture t = blank(RT_TEX_NOISE);
         t.scale = scale;
         t.perlin = (int)r.perlins.size();
@@ -857,14 +875,16 @@ class material {
   protected:
     int memo(rtamd::Recorder &r, const rt_material &m) const {
         r.materials.push_back(m);
-        return r.material_ids[this] = (int)r.materials.size() - 1;
+        recorded_by = r.serial;
+        return recorded_as = (int)r.materials.size() - 1;
     }
     bool known(rtamd::Recorder &r, int &id) const {
-        auto it = r.material_ids.find(this);
-        if (it == r.material_ids.end()) return false;
-        id = it->second;
+        if (recorded_by != r.serial) return false;
+        id = recorded_as;
         return true;
     }
+    mutable uint64_t recorded_by = 0; // the recorder (Recorder::serial) that holds this material ...
+    mutable int recorded_as = -1;     // ... at this index
 };
 
 class lambertian : public material {
@@ -1187,6 +1207,7 @@ class sphere : public hittable {
     void record(rtamd::Recorder &r) const override {
         rt_prim p;
         memset(&p, 0, sizeof(p));
+        if (r.counting) return r.add_prim(p); // (the counting pass only counts)
         p.type = RT_PRIM_SPHERE;
         p.material = mat->record(r);
         p.flags = is_moving ? RT_PRIM_FLAG_MOVING : 0;
@@ -1238,6 +1259,7 @@ class quad : public hittable {
     void record(rtamd::Recorder &r) const override {
         rt_prim p;
         memset(&p, 0, sizeof(p));
+        if (r.counting) return r.add_prim(p);
         p.type = RT_PRIM_QUAD;
         p.material = mat->record(r);
         for (int k = 0; k < 3; k++) {
@@ -1276,54 +1298,122 @@ inline shared_ptr<hittable_list> box(const point3 &a, const point3 &b, shared_pt
 // bvh.h.  The renderer builds its own tree over the flattened primitives; what it takes from
 // this class is the ORDER in which the reference's tree would test its leaves (the recursive
 // std::sort by box minimum along the longest axis, bvh.h:48-75), because that order decides
-// which of two coincident primitives wins.  The tree itself is kept as well, for host code
-// that calls hit() or walks it through get_left_child() / get_right_child().
+// which of two coincident primitives wins.  The reference's constructor is the slow part of a
+// large scene (10 s for 10^6 primitives: every comparison copies two shared_ptr and makes two
+// virtual calls, every level sorts again), so the order is computed here on plain arrays: the
+// boxes are fetched once, every range is sorted as {key, index} pairs by the same std::sort with
+// the same comparison outcomes (so the permutation is the one the reference's sort produces,
+// whatever it does with equal keys), and the two halves of a large range are sorted on two
+// threads.  The tree itself, for host code that calls hit() or walks get_left_child() /
+// get_right_child(), is made of the same ranges and is built node by node when first asked for.
 class bvh_node : public hittable {
   public:
     bvh_node(hittable_list list) : bvh_node(list.objects, 0, list.objects.size()) {}
+    // (like the reference's, this constructor leaves objects[start, end) in the tree's leaf order)
     bvh_node(std::vector<shared_ptr<hittable>> &objects, size_t start, size_t end) {
-        bbox = aabb::empty; // bvh.h:50-52: the box of the range as it is handed in
-        for (size_t i = start; i < end; i++) bbox = aabb(bbox, objects[i]->bounding_box());
-        const size_t span = end - start;
-        if (span == 1) {
-            left = right = objects[start];
-        } else if (span == 2) {
-            left = objects[start];
-            right = objects[start + 1];
-        } else if (span > 2) {
-            const int axis = bbox.longest_axis();
-            std::sort(objects.begin() + start, objects.begin() + end,
-                      [axis](const shared_ptr<hittable> a, const shared_ptr<hittable> b) {
-                          return a->bounding_box().axis_interval(axis).min < b->bounding_box().axis_interval(axis).min;
-                      });
-            const size_t mid = start + span / 2;
-            left = make_shared<bvh_node>(objects, start, mid);
-            right = make_shared<bvh_node>(objects, mid, end);
+        const size_t n = end > start ? end - start : 0;
+        std::vector<aabb> boxes(n);
+        for (size_t i = 0; i < n; i++) boxes[i] = objects[start + i]->bounding_box();
+        std::vector<Key> keys(n);
+        for (size_t i = 0; i < n; i++) keys[i].index = (uint32_t)i;
+        order_range(boxes, keys.data(), 0, n, 0);
+        auto sh = make_shared<Ranges>();
+        sh->leaves.resize(n);
+        sh->boxes.resize(n);
+        for (size_t i = 0; i < n; i++) {
+            sh->leaves[i] = objects[start + keys[i].index];
+            sh->boxes[i] = boxes[keys[i].index];
         }
-        leaves.assign(objects.begin() + start, objects.begin() + end); // left to right, each leaf once
+        std::copy(sh->leaves.begin(), sh->leaves.end(), objects.begin() + start);
+        all = sh;
+        first = 0;
+        last = n;
+        bbox = box_of(sh->boxes, 0, n);
     }
     bool hit(const ray &r, interval ray_t, hit_record &rec) const override { // bvh.h:77-88
+        children();
         if (!left || !bbox.hit(r, ray_t)) return false;
         const bool hit_left = left->hit(r, ray_t, rec);
         const bool hit_right = right->hit(r, interval(ray_t.min, hit_left ? rec.t : ray_t.max), rec);
         return hit_left || hit_right;
     }
     aabb bounding_box() const override { return bbox; }
-    shared_ptr<hittable> get_left_child() const override { return left; }   // bvh.h:143-149
-    shared_ptr<hittable> get_right_child() const override { return right; }
+    shared_ptr<hittable> get_left_child() const override { // bvh.h:143-149
+        children();
+        return left;
+    }
+    shared_ptr<hittable> get_right_child() const override {
+        children();
+        return right;
+    }
     void record(rtamd::Recorder &r) const override {
         r.begin_bvh();
-        for (const auto &o : leaves) o->record(r);
+        for (size_t i = first; i < last; i++) all->leaves[i]->record(r); // left to right, each leaf once
         r.end_bvh();
     }
     void print() const override {
-        for (const auto &o : leaves) o->print();
+        for (size_t i = first; i < last; i++) all->leaves[i]->print();
     }
 
   private:
-    shared_ptr<hittable> left, right;
-    std::vector<shared_ptr<hittable>> leaves;
+    struct Key {
+        float key;
+        uint32_t index;
+    };
+    struct Ranges { // the whole tree's leaves in their final order, and their boxes
+        std::vector<shared_ptr<hittable>> leaves;
+        std::vector<aabb> boxes;
+    };
+    // a node below the root: the range [first, last) of the root's leaves (bvh.h:54-71 splits at the middle)
+    bvh_node(shared_ptr<const Ranges> ranges, size_t first_leaf, size_t last_leaf)
+        : all(std::move(ranges)), first(first_leaf), last(last_leaf) {
+        bbox = box_of(all->boxes, first, last);
+    }
+    static aabb box_of(const std::vector<aabb> &boxes, size_t a, size_t b) { // bvh.h:50-52
+        aabb box = aabb::empty;
+        for (size_t i = a; i < b; i++) box = aabb(box, boxes[i]);
+        return box;
+    }
+    // bvh.h:48-75 on indices: keys[a, b) holds the indices of the range in their current order
+    static void order_range(const std::vector<aabb> &boxes, Key *keys, size_t a, size_t b, int forks) {
+        const size_t span = b - a;
+        if (span <= 2) return;
+        aabb box = aabb::empty;
+        for (size_t i = a; i < b; i++) box = aabb(box, boxes[keys[i].index]);
+        const int axis = box.longest_axis();
+        for (size_t i = a; i < b; i++) keys[i].key = boxes[keys[i].index].axis_interval(axis).min;
+        std::sort(keys + a, keys + b, [](const Key &x, const Key &y) { return x.key < y.key; });
+        const size_t mid = a + span / 2;
+        if (span >= 32768 && forks < 4) { // the halves are independent: up to 16 threads
+            std::thread other(order_range, std::cref(boxes), keys, a, mid, forks + 1);
+            order_range(boxes, keys, mid, b, forks + 1);
+            other.join();
+        } else {
+            order_range(boxes, keys, a, mid, forks);
+            order_range(boxes, keys, mid, b, forks);
+        }
+    }
+    void children() const {
+        std::call_once(built, [this]() {
+            const size_t span = last - first;
+            if (span == 1) {
+                left = right = all->leaves[first];
+            } else if (span == 2) {
+                left = all->leaves[first];
+                right = all->leaves[first + 1];
+            } else if (span > 2) {
+                const size_t mid = first + span / 2;
+                left = shared_ptr<bvh_node>(new bvh_node(all, first, mid));
+                right = shared_ptr<bvh_node>(new bvh_node(all, mid, last));
+            }
+        });
+    }
+
+    shared_ptr<const Ranges> all;
+    size_t first = 0, last = 0;
     aabb bbox;
+    mutable std::once_flag built;
+    mutable shared_ptr<hittable> left, right;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -1385,6 +1475,15 @@ class camera {
     // library is printed and the process exits, since no image can be produced.
     void render(const hittable &world, const char *file_name) {
         auto t0 = std::chrono::steady_clock::now();
+        // RTAMD_TIMING=1: where the time of this call goes, on stderr
+        const bool timing = getenv("RTAMD_TIMING") && atoi(getenv("RTAMD_TIMING")) != 0;
+        auto t_lap = t0;
+        auto lap = [&](const char *what) {
+            if (!timing) return;
+            auto now = std::chrono::steady_clock::now();
+            std::cerr << "[rtamd] " << what << ": " << std::chrono::duration<double, std::milli>(now - t_lap).count() << " ms\n";
+            t_lap = now;
+        };
         // objects that several wrappers share become sub-scenes with instances (RTAMD_INSTANCES=0:
         // everything written out, as before); a scene that shares nothing records exactly as it did
         rtamd::Recorder counted, rec;
@@ -1393,10 +1492,12 @@ class camera {
             counted.counting = true;
             world.record(counted);
             if (counted.any_shared()) rec.shared = &counted.seen;
+            rec.prims.reserve(counted.n_counted); // (at most: shared objects are recorded once)
         }
         world.record(rec);
         rt_scene_desc sd = rec.desc();
         rt_camera_desc cd = descriptor();
+        lap("scene graph recorded");
         const char *dump = getenv("RTAMD_DUMP_SCENE"); // fixture generation: write the flat scene and stop
         if (dump) {
             if (rt_scene_file_save(&sd, dump) != RT_OK) die("rt_scene_file_save");
@@ -1449,6 +1550,7 @@ class camera {
         }
         rt_scene *scene = nullptr;
         if (rt_scene_create(&sd, devs.size() == 1 ? devs[0] : device, 0, &scene) != RT_OK) die("rt_scene_create");
+        lap("rt_scene_create (tree, upload; the first call also starts the HIP runtime)");
         int pass = pass_samples, every = write_every;
         std::string ckpt = checkpoint;
         if (const char *e = getenv("RTAMD_PASS_SPP")) pass = atoi(e);
@@ -1468,11 +1570,13 @@ class camera {
             opts.seed = seed;
             opts.mode = RT_MODE_MEGAKERNEL;
             if (rt_render(scene, &cd, &opts, accum.data(), &stats) != RT_OK) die("rt_render");
+            lap("rt_render");
             std::vector<uint8_t> rgb((size_t)W * H * 3);
             if (rt_tonemap_u8(accum.data(), (int64_t)W * H, frame.pixel_samples_scale, rgb.data()) != RT_OK)
                 die("rt_tonemap_u8");
             if (!rtamd::write_png_rgb8(file_name, W, H, rgb.data()))
                 std::cerr << "ERROR: could not write '" << file_name << "'.\n";
+            lap("tone map and PNG");
         }
         rt_scene_destroy(scene);
         std::clog << "\rDone.\n";

@@ -183,6 +183,52 @@ int main() {
         }
         CHECK(both > 200);
     }
+    {   // The order of a bvh_node's leaves is the one the recursion of bvh.h:48-75 produces when it is
+        // written down plainly (sort the range of shared_ptr by box minimum along the longest axis of
+        // the range's box, halve, recurse), equal keys included: positions on a coarse lattice give
+        // thousands of them, and 70 000 objects reach the ranges that are sorted on several threads.
+        struct plain {
+            static void order(std::vector<shared_ptr<hittable>> &o, size_t a, size_t b) {
+                if (b - a <= 2) return;
+                aabb box = aabb::empty;
+                for (size_t i = a; i < b; i++) box = aabb(box, o[i]->bounding_box());
+                const int axis = box.longest_axis();
+                std::sort(o.begin() + a, o.begin() + b, [axis](const shared_ptr<hittable> x, const shared_ptr<hittable> y) {
+                    return x->bounding_box().axis_interval(axis).min < y->bounding_box().axis_interval(axis).min;
+                });
+                const size_t mid = a + (b - a) / 2;
+                order(o, a, mid);
+                order(o, mid, b);
+            }
+        };
+        auto grey = make_shared<lambertian>(color(0.5f, 0.5f, 0.5f));
+        for (int n : {7, 1000, 70000}) {
+            std::vector<shared_ptr<hittable>> objs;
+            for (int i = 0; i < n; i++)
+                objs.push_back(make_shared<sphere>(point3(float(int(random_float(0, 40))), float(int(random_float(0, 6))),
+                                                          float(int(random_float(0, 40)))), 0.25f, grey));
+            std::vector<shared_ptr<hittable>> expect = objs, given = objs;
+            plain::order(expect, 0, expect.size());
+            bvh_node tree(given, 0, given.size());
+            CHECK(given == expect); // the caller's vector is left in leaf order, as by the reference
+            // ... and the tree's own leaves, walked left to right, are that order
+            std::vector<shared_ptr<hittable>> walked;
+            struct walk {
+                static void go(const shared_ptr<hittable> &h, std::vector<shared_ptr<hittable>> &out) {
+                    auto l = h->get_left_child(), r = h->get_right_child();
+                    if (!l && !r) {
+                        out.push_back(h);
+                        return;
+                    }
+                    go(l, out);
+                    if (r != l) go(r, out);
+                }
+            };
+            walk::go(tree.get_left_child(), walked);
+            if (tree.get_right_child() != tree.get_left_child()) walk::go(tree.get_right_child(), walked);
+            CHECK(walked == expect);
+        }
+    }
     if (g_failures) {
         fprintf(stderr, "%d check(s) failed\n", g_failures);
         return 1;
