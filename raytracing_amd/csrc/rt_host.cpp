@@ -514,10 +514,14 @@ static int impl_rt_scene_create(const rt_scene_desc *d, int device, uint32_t fla
             s->info.device_bytes += bytes;
         }
     }
-    if (env_int("RT_AMD_DEBUG", 0))
+    if (env_int("RT_AMD_DEBUG", 0)) {
         fprintf(stderr, "librt_amd: render geometry grid %d block %d lds %d (scene %d records %d), resident blocks/CU %d\n",
                 s->geom.grid, s->geom.block, s->geom.lds_bytes, (int)s->geom.lds_scene, s->geom.lds_records,
                 rtl::mega_blocks_per_cu(s->geom.block, s->geom.lds_bytes, s->geom.lds_scene));
+        const double all_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build0).count();
+        fprintf(stderr, "librt_amd: scene of %d primitives: flattening and tree %.1f ms, upload and kernel set-up %.1f ms\n", n,
+                build_ms, all_ms - build_ms);
+    }
     s->info.lds_resident = s->geom.lds_scene ? 1 : 0;
     *out = s;
     return RT_OK;
