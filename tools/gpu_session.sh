@@ -1,8 +1,8 @@
 #!/bin/bash
 # GPU box: tests, soak runs (every image of a scene equal to the first), A/B of library variants and
 # the wave-level schedule statistics, each step under its own time limit; stops at the first failure.
-# usage: tools/r3_session.sh <tag> <variants for the A/B ("default" = in-tree)...>
-TAG=${1:-r3}; shift
+# usage: tools/gpu_session.sh <tag> <variants for the A/B ("default" = in-tree)...>
+TAG=${1:-session}; shift
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
