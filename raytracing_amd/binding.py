@@ -160,6 +160,11 @@ class Scene:
         check(fn(self.handle, rays.ctypes.data, len(rays), tmin, tmax, hits.ctypes.data))
         return hits
 
+    def trace_device(self, d_rays_ptr, n, d_hits_ptr, stream=0, tmin=0.001, tmax=np.inf, sched=False):
+        """The same on device buffers (n rt_ray records in, n rt_hit records out), enqueued on `stream`."""
+        fn = lib().rt_trace_batch_sched_device if sched else lib().rt_trace_batch_device
+        check(fn(self.handle, C.c_void_p(d_rays_ptr), n, tmin, tmax, C.c_void_p(d_hits_ptr), C.c_void_p(stream)))
+
     def render(self, cam, sample_count, sample_begin=0, seed=0, counters=False, accum=None,
                mode=abi.RT_MODE_MEGAKERNEL):
         """Host-buffer render: returns (accum[H,W,3] fp32 sums, RenderStats)."""
