@@ -342,6 +342,33 @@ def test_cost_ordered_strips_change_nothing(monkeypatch):
     assert np.array_equal(results[0][0], results[0][1]) and np.array_equal(results[0][0], results[0][3])
 
 
+def test_hits_shaded_together_change_nothing(monkeypatch):
+    """Scanned scenes with noise textures end a miss's path at once and let hits wait until 48 lanes
+    hold one before they are shaded (RT_AMD_SHADE_MIN; 1 = the plain loop that shades in every
+    iteration).  Which lanes shade together must not show: the same image and ray count bit for bit
+    for every threshold, odd image sizes and a depth limit of 1 included, and for a scene without
+    noise that is pushed onto the waiting loop."""
+    B = _binding()
+    for scene, width, depth in (("perlin_spheres", 0, 0), ("simple_light", 131, 0), ("simple_light", 64, 1),
+                                ("cornell_box", 97, 0)):
+        arrays, cam, _ = load_scene(scene)
+        if width:
+            cam.image_width = width
+        if depth:
+            cam.max_depth = depth
+        results = []
+        for shade_min in ("1", "0", "17", "64"):  # "0": the scene's own choice
+            monkeypatch.setenv("RT_AMD_SHADE_MIN", shade_min)
+            sc = B.Scene(arrays)
+            img, st = sc.render(cam, 5, seed=11)
+            results.append((img, st.rays, st.paths))
+            sc.close()
+        monkeypatch.delenv("RT_AMD_SHADE_MIN")
+        assert results[0][0].std() > 0
+        for img, rays, paths in results[1:]:
+            assert np.array_equal(img, results[0][0]) and rays == results[0][1] and paths == results[0][2]
+
+
 def test_eight_way_sample_split_equals_one_render():
     """The multi-GPU partition at the headline size (400x225, 100 spp per GPU, 8 GPUs): the eight
     sample ranges of spp_split.sample_range, rendered one after the other into separate images and
