@@ -1394,26 +1394,41 @@ class bvh_node : public hittable {
         }
     }
     void children() const {
-        std::call_once(built, [this]() {
-            const size_t span = last - first;
-            if (span == 1) {
-                left = right = all->leaves[first];
-            } else if (span == 2) {
-                left = all->leaves[first];
-                right = all->leaves[first + 1];
-            } else if (span > 2) {
-                const size_t mid = first + span / 2;
-                left = shared_ptr<bvh_node>(new bvh_node(all, first, mid));
-                right = shared_ptr<bvh_node>(new bvh_node(all, mid, last));
-            }
-        });
+        if (built.load(std::memory_order_acquire)) return;
+        static std::mutex building; // (one for all nodes: a node is built once, in microseconds)
+        std::lock_guard<std::mutex> lock(building);
+        if (built.load(std::memory_order_relaxed)) return;
+        const size_t span = last - first;
+        if (span == 1) {
+            left = right = all->leaves[first];
+        } else if (span == 2) {
+            left = all->leaves[first];
+            right = all->leaves[first + 1];
+        } else if (span > 2) {
+            const size_t mid = first + span / 2;
+            left = shared_ptr<bvh_node>(new bvh_node(all, first, mid));
+            right = shared_ptr<bvh_node>(new bvh_node(all, mid, last));
+        }
+        built.store(true, std::memory_order_release);
     }
 
     shared_ptr<const Ranges> all;
     size_t first = 0, last = 0;
     aabb bbox;
-    mutable std::once_flag built;
+    mutable std::atomic<bool> built{false};
     mutable shared_ptr<hittable> left, right;
+
+  public:
+    // copyable like the reference's class (a copy builds its own children when asked)
+    bvh_node(const bvh_node &o) : hittable(o), all(o.all), first(o.first), last(o.last), bbox(o.bbox) {}
+    bvh_node &operator=(const bvh_node &o) {
+        if (this != &o) {
+            all = o.all, first = o.first, last = o.last, bbox = o.bbox;
+            left.reset(), right.reset();
+            built.store(false, std::memory_order_release);
+        }
+        return *this;
+    }
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -227,6 +227,11 @@ int main() {
             walk::go(tree.get_left_child(), walked);
             if (tree.get_right_child() != tree.get_left_child()) walk::go(tree.get_right_child(), walked);
             CHECK(walked == expect);
+            bvh_node copy = tree; // copies share the leaves and build their own children
+            std::vector<shared_ptr<hittable>> again;
+            walk::go(copy.get_left_child(), again);
+            if (copy.get_right_child() != copy.get_left_child()) walk::go(copy.get_right_child(), again);
+            CHECK(again == expect);
         }
     }
     if (g_failures) {
