@@ -129,7 +129,11 @@ typedef struct rt_group {
  * time do not grow with the number of instances.  Results equal those of the same scene with
  * every instance written out as primitives (loose primitives first, in their order, then the
  * instances in theirs: that order decides ties between equal hits); rt_hit.prim names the
- * primitive of the sub-scene. */
+ * primitive of the sub-scene.  A range holds primitives only: a shared object inside a shared
+ * object is given as one more instance of the world per placement of the outer object, whose
+ * chain is the inner object's wrappers followed by the outer placement's (innermost first, as in
+ * every chain), so that a ray passes the operations in the order of the reference's nested hit()
+ * calls. */
 typedef struct rt_instance {
     int32_t first_prim, n_prims;
     int32_t xform; /* index into chains[], -1 = none */
