@@ -310,6 +310,17 @@ int rt_trace_batch_sched(rt_scene *scene, const rt_ray *rays, int64_t n_rays, fl
 int rt_trace_batch_sched_device(rt_scene *scene, const rt_ray *d_rays, int64_t n_rays, float tmin,
                                 float tmax, rt_hit *d_hits, void *stream);
 
+/* The closest-hit query reduced to what decides parity with the reference (world.hit, camera.h:148:
+ * whether anything is hit, which primitive, at which parameter): prim[i] = the primitive of ray i's
+ * closest hit on (tmin, tmax) or -1, t[i] = its parameter (tmax for a miss), both bit for bit what
+ * rt_trace_batch reports in rt_hit.prim and rt_hit.t.  Trees are walked by the render kernel's own
+ * traversal (as rt_trace_batch_sched), scanned scenes by the scan.  No point, normal or texture
+ * coordinates are derived, so this is the rate of intersection and traversal alone. */
+int rt_closest_hits(rt_scene *scene, const rt_ray *rays, int64_t n_rays, float tmin, float tmax, int32_t *prim,
+                    float *t);
+int rt_closest_hits_device(rt_scene *scene, const rt_ray *d_rays, int64_t n_rays, float tmin, float tmax,
+                           int32_t *d_prim, float *d_t, void *stream);
+
 /* Replaces the sample loop of camera::render (camera.h:40-47) for samples
  * [sample_begin, sample_begin+sample_count) of every pixel: ADDS the radiance
  * sum of those samples to accum (image_height*image_width*3 floats, row-major

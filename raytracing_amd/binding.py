@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(os.path.dirname(os.path.
 # every symbol include/rt_amd.h declares
 EXPORTS = ["rt_last_error", "rt_abi_version", "rt_device_count", "rt_camera_initialize",
            "rt_scene_create", "rt_scene_destroy", "rt_scene_get_info", "rt_scene_read_nodes", "rt_trace_batch",
-           "rt_trace_batch_device", "rt_trace_batch_sched", "rt_trace_batch_sched_device", "rt_render", "rt_render_device", "rt_render_device_static", "rt_tonemap_u8", "rt_tonemap_u8_device",
+           "rt_trace_batch_device", "rt_trace_batch_sched", "rt_trace_batch_sched_device", "rt_closest_hits", "rt_closest_hits_device", "rt_render", "rt_render_device", "rt_render_device_static", "rt_tonemap_u8", "rt_tonemap_u8_device",
            "rt_film_create", "rt_film_destroy", "rt_film_render", "rt_film_snapshot", "rt_film_wait",
            "rt_film_upload", "rt_multi_create", "rt_multi_destroy", "rt_multi_render", "rt_profile_begin", "rt_profile_end", "rt_scene_file_save", "rt_scene_file_load",
            "rt_scene_file_free"]
@@ -52,6 +52,9 @@ def lib():
                                             C.c_void_p, C.c_void_p]
         L.rt_trace_batch_sched.argtypes = L.rt_trace_batch.argtypes
         L.rt_trace_batch_sched_device.argtypes = L.rt_trace_batch_device.argtypes
+        L.rt_closest_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+        L.rt_closest_hits_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_void_p,
+                                             C.c_void_p, C.c_void_p]
         L.rt_render.argtypes = [C.c_void_p, C.POINTER(abi.CameraDesc), C.POINTER(abi.RenderOpts),
                                 C.c_void_p, C.POINTER(abi.RenderStats)]
         L.rt_render_device.argtypes = [C.c_void_p, C.POINTER(abi.CameraDesc),
@@ -159,6 +162,18 @@ class Scene:
         fn = lib().rt_trace_batch_sched if sched else lib().rt_trace_batch
         check(fn(self.handle, rays.ctypes.data, len(rays), tmin, tmax, hits.ctypes.data))
         return hits
+
+    def closest_hits(self, rays, tmin=0.001, tmax=np.inf):
+        """rt_closest_hits: (prim[n] int32, -1 for a miss; t[n] float32) of a ray batch."""
+        rays = np.ascontiguousarray(rays, abi.RAY_DT)
+        prim = np.zeros(len(rays), np.int32)
+        t = np.zeros(len(rays), np.float32)
+        check(lib().rt_closest_hits(self.handle, rays.ctypes.data, len(rays), tmin, tmax, prim.ctypes.data, t.ctypes.data))
+        return prim, t
+
+    def closest_hits_device(self, d_rays_ptr, n, d_prim_ptr, d_t_ptr, stream=0, tmin=0.001, tmax=np.inf):
+        check(lib().rt_closest_hits_device(self.handle, C.c_void_p(d_rays_ptr), n, tmin, tmax, C.c_void_p(d_prim_ptr),
+                                           C.c_void_p(d_t_ptr), C.c_void_p(stream)))
 
     def trace_device(self, d_rays_ptr, n, d_hits_ptr, stream=0, tmin=0.001, tmax=np.inf, sched=False):
         """The same on device buffers (n rt_ray records in, n rt_hit records out), enqueued on `stream`."""

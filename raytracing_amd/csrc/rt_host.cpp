@@ -1028,6 +1028,67 @@ int rt_trace_batch_sched_device(rt_scene *s, const rt_ray *d_rays, int64_t n, fl
     return RT_OK;
 }
 
+int rt_closest_hits_device(rt_scene *s, const rt_ray *d_rays, int64_t n, float tmin, float tmax, int32_t *d_prim,
+                           float *d_t, void *stream_v) {
+    if (!s || n < 0 || (n > 0 && (!d_rays || !d_prim || !d_t))) return fail(RT_ERR_ARG, "bad argument");
+    if (n == 0) return RT_OK;
+    int rc = set_device(s->device);
+    if (rc != RT_OK) return rc;
+    hipStream_t stream = (hipStream_t)stream_v;
+    const bool tree = s->dev.traversal == rtc::TRAV_BVH;
+    // (as rt_trace_batch_sched_device: record set 0's stack overflow area and a spare counter word)
+    if (tree)
+        for (int k = 0; k < kSets; k++)
+            if (s->ev_free_valid[k]) RT_HIP(hipStreamWaitEvent(stream, s->ev_free[k], 0));
+    const LaunchGeom lg = s->geom;
+    const Tunables tn = read_tunables(lg.lds_scene);
+    rt_render_opts o;
+    memset(&o, 0, sizeof(o));
+    RenderParams rp = base_params(1, 1, 1, &o, 0, 1, lg, tn);
+    rp.stack_spill = s->stack_spill[0];
+    rp.next_chunk = reinterpret_cast<unsigned *>(s->d_words + 6);
+    rtc::DevScene dev = s->dev;
+    dev.lds_records = lg.lds_records;
+    dev.lds_perlins = lg.lds_perlins;
+    if (tree) RT_HIP(hipMemsetAsync(s->d_words + 6, 0, sizeof(unsigned long long), stream));
+    if (dev.n_inst > 0)
+        RT_HIP(rtl::launch_closest_inst(dev, rp, lg, d_rays, n, tmin, tmax, d_prim, d_t, stream));
+    else
+        RT_HIP(rtl::launch_closest(dev, rp, lg, d_rays, n, tmin, tmax, d_prim, d_t, stream));
+    if (tree) {
+        if (!s->ev_free[0]) RT_HIP(hipEventCreateWithFlags(&s->ev_free[0], hipEventDisableTiming));
+        RT_HIP(hipEventRecord(s->ev_free[0], stream));
+        s->ev_free_valid[0] = true;
+    }
+    return RT_OK;
+}
+
+int rt_closest_hits(rt_scene *s, const rt_ray *rays, int64_t n, float tmin, float tmax, int32_t *prim, float *t) {
+    if (!s || n < 0 || (n > 0 && (!rays || !prim || !t))) return fail(RT_ERR_ARG, "bad argument");
+    if (n == 0) return RT_OK;
+    int rc = set_device(s->device);
+    if (rc != RT_OK) return rc;
+    rt_ray *d_rays = nullptr;
+    int32_t *d_prim = nullptr;
+    float *d_t = nullptr;
+    hipError_t e = hipMalloc((void **)&d_rays, sizeof(rt_ray) * n);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_prim, sizeof(int32_t) * n);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_t, sizeof(float) * n);
+    if (e == hipSuccess) e = hipMemcpy(d_rays, rays, sizeof(rt_ray) * n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        rc = rt_closest_hits_device(s, d_rays, n, tmin, tmax, d_prim, d_t, nullptr);
+        if (rc == RT_OK) e = hipDeviceSynchronize();
+        if (rc == RT_OK && e == hipSuccess) e = hipMemcpy(prim, d_prim, sizeof(int32_t) * n, hipMemcpyDeviceToHost);
+        if (rc == RT_OK && e == hipSuccess) e = hipMemcpy(t, d_t, sizeof(float) * n, hipMemcpyDeviceToHost);
+    }
+    if (d_rays) hipFree(d_rays);
+    if (d_prim) hipFree(d_prim);
+    if (d_t) hipFree(d_t);
+    if (rc != RT_OK) return rc;
+    if (e != hipSuccess) return fail(RT_ERR_HIP, "closest hits: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
 namespace {
 int trace_batch_host(rt_scene *s, const rt_ray *rays, int64_t n, float tmin, float tmax, rt_hit *hits, bool sched) {
     if (!s || n < 0 || (n > 0 && (!rays || !hits))) return fail(RT_ERR_ARG, "bad argument");

@@ -545,9 +545,11 @@ __device__ __forceinline__ rt_hit make_hit_record(const DevScene &sc, const Scen
 }
 
 // Closest hit for a batch of rays, one whole ray per lane, scene read from global memory.
-template <int TRAV>
+// IDS: only the closest primitive and its parameter are written, as two arrays (ids: -1 for a miss).
+template <int TRAV, bool IDS = false>
 __global__ void __launch_bounds__(RT_TRACE_THREADS)
-trace_batch(DevScene sc, const rt_ray *rays, long long n_rays, float tmin, float tmax, rt_hit *hits) {
+trace_batch(DevScene sc, const rt_ray *rays, long long n_rays, float tmin, float tmax, rt_hit *hits, int *prim_out,
+            float *t_out) {
     extern __shared__ f4 smem[];
     typedef TravStack<int, RT_TRACE_THREADS> Stack;
     const Stack st = lane_stack<int, false, RT_TRACE_THREADS>(smem, sc, sc.stack_cap, nullptr);
@@ -565,18 +567,25 @@ trace_batch(DevScene sc, const rt_ray *rays, long long n_rays, float tmin, float
             h = trace_linear<false>(sc, vw, r, tmin, tmax, cn);
         else
             h = trace_bvh<false, Stack, false>(sc, vw, r, tmin, tmax, st, cn);
-        hits[k] = make_hit_record(sc, vw, r, h);
+        if constexpr (IDS) {
+            prim_out[k] = h.slot < 0 ? -1 : vw.rec_i[h.slot].w;
+            t_out[k] = h.t;
+        } else {
+            hits[k] = make_hit_record(sc, vw, r, h);
+        }
     }
 }
 
 // The same query through the render kernel's own traversal: the launch shape, the LDS copy of
 // the scene (or of the tree's top), the 16-bit / spilling stacks and the decoupled scheduling of
 // render_mega_bvh (wave_traverse: blocks of node steps, parked leaves), with the caller's rays
-// in place of paths.  A wave takes 64 consecutive rays at a time from a global counter; lanes
-// whose ray is done write its record and take the next one.
-template <bool LDS_SCENE, bool COOP = false>
+// in place of paths.  A wave takes a run of consecutive rays at a time from a global counter (64 for
+// small batches, up to 2048 for large ones: with 64 the one counter is what a 4 x 10^7-ray batch
+// waits for, 12 ns per wave and run); lanes whose ray is done write its record and take the next one.
+template <bool LDS_SCENE, bool COOP = false, bool IDS = false>
 __global__ void __launch_bounds__(RT_MEGA_MAX_THREADS, RT_MEGA_WAVES_PER_SIMD)
-trace_sched(DevScene sc, RenderParams rp, const rt_ray *rays, long long n_rays, float tmin, float tmax, rt_hit *hits) {
+trace_sched(DevScene sc, RenderParams rp, const rt_ray *rays, long long n_rays, float tmin, float tmax, rt_hit *hits,
+            int *prim_out, float *t_out) {
     extern __shared__ f4 smem[];
     SceneView vw = global_view(sc);
     f4 *free_lds = smem;
@@ -595,7 +604,11 @@ trace_sched(DevScene sc, RenderParams rp, const rt_ray *rays, long long n_rays, 
     f4 *coop_stage = COOP ? smem + rp.coop_f4 + (size_t)(threadIdx.x >> 6) * RT_COOP_F4_PER_WAVE : nullptr;
     const int lane = threadIdx.x & 63;
     const unsigned long long lane_mask_lt = (1ull << lane) - 1ull;
-    const unsigned long long n_batches = (unsigned long long)((n_rays + 63) / 64);
+    // rays per run: about eight runs per wave of the grid, whole multiples of 64
+    const long long n_waves = (long long)gridDim.x * (blockDim.x >> 6);
+    long long run = (n_rays / (n_waves * 8) + 63) / 64 * 64;
+    run = run < 64 ? 64 : (run > 2048 ? 2048 : run);
+    const unsigned long long n_batches = (unsigned long long)((n_rays + run - 1) / run);
     unsigned long long *next_batch = reinterpret_cast<unsigned long long *>(rp.next_chunk);
     long long k = 0, k_end = 0; // the wave's current batch of rays
     bool exhausted = false;
@@ -612,7 +625,12 @@ trace_sched(DevScene sc, RenderParams rp, const rt_ray *rays, long long n_rays, 
             h.t = tv.best_t;
             h.slot = tv.best_slot;
             if (RT_FEAT_INSTANCE) h.inst = tv.best_inst;
-            hits[mine] = make_hit_record(sc, vw, ray, h);
+            if constexpr (IDS) {
+                prim_out[mine] = h.slot < 0 ? -1 : vw.rec_i[h.slot].w;
+                t_out[mine] = h.t;
+            } else {
+                hits[mine] = make_hit_record(sc, vw, ray, h);
+            }
             state = ST_IDLE;
         }
         // idle lanes take the next rays of the batch; an empty batch is replaced first
@@ -627,8 +645,8 @@ trace_sched(DevScene sc, RenderParams rp, const rt_ray *rays, long long n_rays, 
                     exhausted = true;
                     break;
                 }
-                k = (long long)b * 64;
-                k_end = k + 64 < n_rays ? k + 64 : n_rays;
+                k = (long long)b * run;
+                k_end = k + run < n_rays ? k + run : n_rays;
             }
             const long long avail = k_end - k;
             const int r = __popcll(need & lane_mask_lt);
@@ -799,6 +817,12 @@ hipError_t RT_LAUNCH_NAME(set_mega_lds_limit)(int bytes) {
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void *)trace_sched<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void *)trace_sched<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void *)trace_sched<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void *)trace_batch<TRAV_BVH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess)
         e = hipFuncSetAttribute((const void *)trace_sched<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 #ifndef RT_INST
     if (e == hipSuccess)
@@ -840,12 +864,33 @@ hipError_t RT_LAUNCH_NAME(launch_trace)(const DevScene &sc, const rt_ray *rays, 
     long long want = (n + RT_TRACE_THREADS - 1) / RT_TRACE_THREADS;
     int grid = (int)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
     const int lds = sc.traversal == TRAV_LINEAR ? 16 : sc.stack_cap * RT_TRACE_THREADS * (int)sizeof(int);
+    int *const no_ids = nullptr;
+    float *const no_t = nullptr;
     if (sc.traversal == TRAV_LINEAR)
         hipLaunchKernelGGL((trace_batch<TRAV_LINEAR>), dim3(grid), dim3(RT_TRACE_THREADS), lds, stream, sc, rays,
-                           n, tmin, tmax, hits);
+                           n, tmin, tmax, hits, no_ids, no_t);
     else
         hipLaunchKernelGGL((trace_batch<TRAV_BVH>), dim3(grid), dim3(RT_TRACE_THREADS), lds, stream, sc, rays, n,
-                           tmin, tmax, hits);
+                           tmin, tmax, hits, no_ids, no_t);
+    return hipGetLastError();
+}
+// The closest primitive and parameter only.  Scenes with a tree go through the render kernel's traversal
+// (rp, lg as for launch_trace_sched), scanned scenes through the whole-ray kernel.
+hipError_t RT_LAUNCH_NAME(launch_closest)(const DevScene &sc, const RenderParams &rp, const LaunchGeom &lg, const rt_ray *rays,
+                          long long n, float tmin, float tmax, int *prim, float *t, hipStream_t stream) {
+    rt_hit *const no_hits = nullptr;
+    if (sc.traversal == TRAV_LINEAR) {
+        long long want = (n + RT_TRACE_THREADS - 1) / RT_TRACE_THREADS;
+        int grid = (int)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
+        hipLaunchKernelGGL((trace_batch<TRAV_LINEAR, true>), dim3(grid), dim3(RT_TRACE_THREADS), 16, stream, sc, rays, n,
+                           tmin, tmax, no_hits, prim, t);
+    } else if (lg.lds_scene) {
+        hipLaunchKernelGGL((trace_sched<true, false, true>), dim3(lg.grid), dim3(lg.block), lg.lds_bytes, stream, sc, rp,
+                           rays, n, tmin, tmax, no_hits, prim, t);
+    } else {
+        hipLaunchKernelGGL((trace_sched<false, false, true>), dim3(lg.grid), dim3(lg.block), lg.lds_bytes, stream, sc, rp,
+                           rays, n, tmin, tmax, no_hits, prim, t);
+    }
     return hipGetLastError();
 }
 
@@ -855,15 +900,15 @@ hipError_t RT_LAUNCH_NAME(launch_trace_sched)(const DevScene &sc, const RenderPa
                               long long n, float tmin, float tmax, rt_hit *hits, hipStream_t stream) {
     if (lg.lds_scene)
         hipLaunchKernelGGL((trace_sched<true>), dim3(lg.grid), dim3(lg.block), lg.lds_bytes, stream, sc, rp, rays, n,
-                           tmin, tmax, hits);
+                           tmin, tmax, hits, (int *)nullptr, (float *)nullptr);
 #ifndef RT_INST
     else if (lg.coop)
         hipLaunchKernelGGL((trace_sched<false, true>), dim3(lg.grid), dim3(lg.block), lg.lds_bytes, stream, sc, rp, rays, n,
-                           tmin, tmax, hits);
+                           tmin, tmax, hits, (int *)nullptr, (float *)nullptr);
 #endif
     else
         hipLaunchKernelGGL((trace_sched<false>), dim3(lg.grid), dim3(lg.block), lg.lds_bytes, stream, sc, rp, rays, n,
-                           tmin, tmax, hits);
+                           tmin, tmax, hits, (int *)nullptr, (float *)nullptr);
     return hipGetLastError();
 }
 #endif // !RT_LEAN

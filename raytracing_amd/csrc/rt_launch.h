@@ -129,6 +129,10 @@ hipError_t launch_trace(const rtc::DevScene &sc, const rt_ray *rays, long long n
                         rt_hit *hits, hipStream_t stream);
 hipError_t launch_trace_sched(const rtc::DevScene &sc, const RenderParams &rp, const LaunchGeom &lg, const rt_ray *rays,
                               long long n, float tmin, float tmax, rt_hit *hits, hipStream_t stream);
+hipError_t launch_closest(const rtc::DevScene &sc, const RenderParams &rp, const LaunchGeom &lg, const rt_ray *rays,
+                          long long n, float tmin, float tmax, int *prim, float *t, hipStream_t stream);
+hipError_t launch_closest_inst(const rtc::DevScene &sc, const RenderParams &rp, const LaunchGeom &lg, const rt_ray *rays,
+                               long long n, float tmin, float tmax, int *prim, float *t, hipStream_t stream);
 hipError_t launch_trace_inst(const rtc::DevScene &sc, const rt_ray *rays, long long n, float tmin, float tmax,
                              rt_hit *hits, hipStream_t stream);
 hipError_t launch_trace_sched_inst(const rtc::DevScene &sc, const RenderParams &rp, const LaunchGeom &lg,

@@ -34,6 +34,9 @@ def test_instanced_scene_traces_like_the_written_out_one(monkeypatch):
         assert info.lds_resident == (0 if flags & abi.RT_SCENE_FORCE_GLOBAL else 1)
         for sched in (False, True):  # the whole-ray kernel and the render kernel's own traversal
             check_two_level_hits(sc.trace(rays, sched=sched), ref, origin)
+        full = sc.trace(rays, sched=True)
+        prim, t = sc.closest_hits(rays)  # the ids-only entry point: the same primitive and parameter
+        assert np.array_equal(prim, full["prim"]) and np.array_equal(t[prim >= 0], full["t"][prim >= 0])
         sc.close()
 
 

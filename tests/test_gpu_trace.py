@@ -32,7 +32,16 @@ def test_trace_matches_reference_records(scene):
     for sched in (False, True):
         hits = sc.trace(rays, tmin, tmax, sched=sched)
         _check_records(hits, ref_hits)
+    _check_ids(sc.closest_hits(rays, tmin, tmax), ref_hits)
     sc.close()
+
+
+def _check_ids(prim_t, ref_hits):
+    """rt_closest_hits against the reference's records: hit / miss, primitive and t, bit for bit."""
+    prim, t = prim_t
+    assert np.array_equal(prim, ref_hits["prim"]), "hit/miss or primitive id differs"
+    m = ref_hits["prim"] >= 0
+    assert np.array_equal(t[m], ref_hits["t"][m]), "t is not bit-exact"
 
 
 def _check_records(hits, ref_hits):
@@ -67,6 +76,7 @@ def test_reference_records_through_the_render_kernels_traversal(scene, monkeypat
         if len(arrays.prims) >= 2:
             assert info.n_nodes > 0 and info.lds_resident == (0 if flags & abi.RT_SCENE_FORCE_GLOBAL else 1)
         _check_records(sc.trace(rays, tmin, tmax, sched=True), ref_hits)
+        _check_ids(sc.closest_hits(rays, tmin, tmax), ref_hits)
         sc.close()
 
 

@@ -1,10 +1,9 @@
 #!/usr/bin/env python3
-"""GPU box: throughput of the batch entry points (rt_trace_batch[_sched]_device) on a ray batch shaped
-like a render's (camera rays of random pixels and three generations of diffuse bounce rays leaving
-their hit points).  These are the parity entry points: every hit comes back as a full rt_hit record
-(t, point, normal, u, v with the device's acosf / atan2f, face, primitive), 32 bytes in and 72 bytes
-out per ray as arrays of structures, so the figure is that of the record generation, not of the
-traversal (the render kernel traces and shades 20 G rays per second; these produce 5-9 G records).
+"""GPU box: throughput of the batch entry points on a ray batch shaped like a render's (camera rays of
+random pixels and three generations of diffuse bounce rays leaving their hit points):
+rt_trace_batch_sched_device and rt_trace_batch_device, which return full rt_hit records (t, point,
+normal, u, v, face, primitive: 32 bytes in and 72 bytes out per ray), and rt_closest_hits_device, which
+returns the primitive and t only: intersection and traversal alone.
 
 usage: python tools/trace_bench.py [scene] [camera rays, default 2^21]
 """
@@ -73,6 +72,24 @@ def main():
         ms = e0.elapsed_time(e1) / reps
         hb = (abi.RAY_DT.itemsize + abi.HIT_DT.itemsize) * n / (ms * 1e-3) / 1e9
         print(f"  {name}: {ms:.3f} ms per batch, {n / ms * 1e-6:.2f} Grays/s, {hb:.0f} GB/s of ray and hit records")
+    # closest primitive and parameter only (rt_closest_hits_device): intersection and traversal alone
+    d_prim = torch.zeros(n, dtype=torch.int32, device="cuda")
+    d_t = torch.zeros(n, dtype=torch.float32, device="cuda")
+    for _ in range(3):
+        sc.closest_hits_device(d_rays.data_ptr(), n, d_prim.data_ptr(), d_t.data_ptr(), stream)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        sc.closest_hits_device(d_rays.data_ptr(), n, d_prim.data_ptr(), d_t.data_ptr(), stream)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 20
+    hit = (d_prim >= 0).float().mean().item()
+    print(f"  rt_closest_hits_device: {ms:.3f} ms per batch, {n / ms * 1e-6:.2f} Grays/s ({100 * hit:.1f} % of the rays hit)")
+    # the same answers as the full records
+    ref = np.frombuffer(d_hits.cpu().numpy().tobytes(), abi.HIT_DT)
+    assert np.array_equal(d_prim.cpu().numpy(), ref["prim"]) and np.array_equal(d_t.cpu().numpy()[ref["prim"] >= 0], ref["t"][ref["prim"] >= 0])
     sc.close()
 
 
