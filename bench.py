@@ -341,6 +341,73 @@ def roofline_of(wl, m, steps_total, spp_per_launch_hint, interval_s=None):
     return r
 
 
+def intersection_alone(wl, st, n_camera=1 << 24, reps=10):
+    """The closest-hit query on its own (rt_closest_hits_device: the render kernel's traversal and the exact
+    primitive tests, no shading, no sampling) on a ray batch shaped like this workload's: camera rays of
+    random pixels and three generations of diffuse bounce rays leaving their hit points, built on the
+    device.  The flops per ray are this workload's own traversal and intersection counts per ray as the
+    instrumented render reported them (the batch is not a render's exact ray set)."""
+    torch, sc, cam = wl.torch, wl.scene, wl.cam
+    from raytracing_amd import binding
+    f = binding.camera_initialize(cam)
+    dev = wl.dev
+    g = torch.Generator(device=dev)
+    g.manual_seed(1)
+    stream = torch.cuda.current_stream().cuda_stream
+    v3 = lambda a: torch.tensor([a[0], a[1], a[2]], dtype=torch.float32, device=dev)
+    px = torch.rand(n_camera, generator=g, device=dev) * f.image_width - 0.5
+    py = torch.rand(n_camera, generator=g, device=dev) * f.image_height - 0.5
+    rays = torch.empty((n_camera, 7), dtype=torch.float32, device=dev)  # rt_ray: origin, direction, time
+    rays[:, 0:3] = v3(f.center)
+    rays[:, 3:6] = v3(f.pixel00_loc) + px[:, None] * v3(f.pixel_delta_u) + py[:, None] * v3(f.pixel_delta_v) - v3(f.center)
+    rays[:, 6] = torch.rand(n_camera, generator=g, device=dev)
+    gens = [rays]
+    for _ in range(3):
+        cur = gens[-1]
+        hits = torch.empty((len(cur), 11), dtype=torch.float32, device=dev)  # rt_hit: prim, face, t, p, normal, u, v
+        sc.trace_device(cur.data_ptr(), len(cur), hits.data_ptr(), stream, sched=True)
+        torch.cuda.synchronize()
+        m = hits.view(torch.int32)[:, 0] >= 0
+        n = int(m.sum().item())
+        if n == 0:
+            break
+        z = torch.rand(n, generator=g, device=dev) * 2 - 1
+        a = torch.rand(n, generator=g, device=dev) * 6.2831853
+        r = torch.sqrt(torch.clamp(1 - z * z, min=0))
+        nxt = torch.empty((n, 7), dtype=torch.float32, device=dev)
+        nxt[:, 0:3] = hits[m, 3:6]
+        nxt[:, 3:6] = hits[m, 6:9] + torch.stack([r * torch.cos(a), r * torch.sin(a), z], 1)
+        nxt[:, 6] = cur[m, 6]
+        gens.append(nxt)
+        del hits
+    batch = torch.cat(gens).contiguous()
+    n = len(batch)
+    prim = torch.empty(n, dtype=torch.int32, device=dev)
+    t = torch.empty(n, dtype=torch.float32, device=dev)
+    for _ in range(2):
+        sc.closest_hits_device(batch.data_ptr(), n, prim.data_ptr(), t.data_ptr(), stream)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        sc.closest_hits_device(batch.data_ptr(), n, prim.data_ptr(), t.data_ptr(), stream)
+    e1.record()
+    torch.cuda.synchronize()
+    seconds = e0.elapsed_time(e1) * 1e-3 / reps
+    flops_per_ray = (W_BOX * st.box_tests + W_SPHERE * st.sphere_tests + W_SPHERE_HIT * st.sphere_hits
+                     + (W_QUAD_AXIS * wl.axis_quads + W_QUAD * (1.0 - wl.axis_quads)) * st.quad_tests
+                     + W_RAY * st.rays) / max(st.rays, 1)
+    achieved = n * flops_per_ray / seconds / 1e12
+    return {"entry": "rt_closest_hits_device", "rays": n, "rays_by_generation": [len(x) for x in gens],
+            "hit_fraction": float((prim >= 0).float().mean().item()), "ms_per_batch": seconds * 1e3,
+            "mrays_per_s": n / seconds * 1e-6, "flops_per_ray": flops_per_ray, "achieved": achieved,
+            "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS,
+            "bytes_per_ray": 28 + 8, "hbm_gb_per_s": n * 36 / seconds * 1e-9,
+            "note": "traversal and exact primitive tests only; flops per ray = this workload's box / sphere / quad test "
+                    "counts per ray from the instrumented render; rays: camera rays of random pixels and three "
+                    "generations of diffuse bounce rays from their hit points"}
+
+
 def load_workload(name, width=0):
     """(arrays, cam) of a golden scene, or of synth1m from the scene program (None if it is absent)."""
     from raytracing_amd import abi
@@ -496,6 +563,15 @@ def run_rank(args):
                              launch_interval_ms=med / steps * 1e3 / max(m["n_launches"] / (steps * args.repeats), 1)),
         }
         print(f"[bench] {scene_name}: {out['value']:.0f} Mpaths/s over {joined} GPU(s)", file=sys.stderr)
+        if world == 1 and not args.no_configs and not args.serial:
+            try:  # (an addition to the line: a failure here must not cost the line itself)
+                out["intersection_alone"] = intersection_alone(wl, st)
+                ia = out["intersection_alone"]
+                print(f"[bench] {scene_name}: closest hits alone {ia['mrays_per_s']:.0f} Mrays/s, frac {ia['frac']:.4f}",
+                      file=sys.stderr)
+            except Exception as e:  # noqa: BLE001
+                out["intersection_alone"] = None
+                print(f"[bench] intersection_alone failed: {e}", file=sys.stderr)
     wl.close()
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

@@ -2,7 +2,7 @@
 """GPU box: throughput of the batch entry points on a ray batch shaped like a render's (camera rays of
 random pixels and three generations of diffuse bounce rays leaving their hit points):
 rt_trace_batch_sched_device and rt_trace_batch_device, which return full rt_hit records (t, point,
-normal, u, v, face, primitive: 32 bytes in and 72 bytes out per ray), and rt_closest_hits_device, which
+normal, u, v, face, primitive: 28 bytes in and 44 bytes out per ray), and rt_closest_hits_device, which
 returns the primitive and t only: intersection and traversal alone.
 
 usage: python tools/trace_bench.py [scene] [camera rays, default 2^21]
